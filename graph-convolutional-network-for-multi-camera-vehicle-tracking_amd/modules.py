@@ -1,0 +1,133 @@
+"""Drop-in `MOTMPNet` for the reference's message-passing network, backed by gfx950 HIP kernels.
+
+Host-side mirror of the reference interface (reference models/mpn.py:144-299, models/mlp.py:4-33):
+same constructor signature, same module tree -- hence the same 34 `state_dict` keys and shapes,
+so `utils.load_pretrained_weights` / `load_state_dict(strict=True)` work unchanged -- same
+`forward(data) -> ({'classified_edges': [Tensor[E,2], ...]}, Tensor[N,32])` contract.
+
+The sub-modules only *hold parameters*; `MOTMPNet.forward` hands the whole forward to the
+C-ABI library (csrc/, include/mtmc_mpn.h) in one call.  There is no PyTorch or CPU fallback:
+without the built extension, or for tensors that are not on a ROCm device, forward raises.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from . import config as _config
+from .config import LayerSpec, MpnSpec
+
+
+class MLP(nn.Module):
+    """Parameter container with the slot layout of the reference MLP (models/mlp.py:11-30):
+    `fc_layers.{slot}` is a Linear, BatchNorm1d(track_running_stats=False), ReLU or Dropout."""
+
+    def __init__(self, input_dim, fc_dims, dropout_p=0.4, use_batchnorm=False, is_classifier=False):
+        super().__init__()
+        self.layers: List[LayerSpec] = _config.plan_mlp(input_dim, fc_dims, dropout_p, use_batchnorm, is_classifier)
+        seq: List[nn.Module] = []
+        for spec in self.layers:
+            seq.append(nn.Linear(spec.in_dim, spec.out_dim))
+            if spec.bn_slot is not None:
+                seq.append(nn.BatchNorm1d(spec.out_dim, track_running_stats=False))
+            if spec.relu:
+                seq.append(nn.ReLU(inplace=True))
+            if spec.dropout_p is not None:
+                seq.append(nn.Dropout(p=spec.dropout_p))
+        self.fc_layers = nn.Sequential(*seq)
+
+    def forward(self, input):
+        from . import ops
+        return ops.mlp_forward(self, input)
+
+
+class MLPGraphIndependent(nn.Module):
+    """Encoder / classifier pair of independent node and edge MLPs (reference models/mpn.py:103-142)."""
+
+    def __init__(self, edge_in_dim=None, node_in_dim=None, edge_out_dim=None, node_out_dim=None,
+                 node_fc_dims=None, edge_fc_dims=None, dropout_p=None, use_batchnorm=None, is_classifier=False):
+        super().__init__()
+        # node MLP first, then edge MLP: parameter creation order fixes the RNG stream, so a
+        # seeded construction yields the reference's initial weights bit for bit
+        self.node_mlp = None if node_in_dim is None else MLP(
+            node_in_dim, list(node_fc_dims) + [node_out_dim], dropout_p, use_batchnorm, is_classifier)
+        self.edge_mlp = None if edge_in_dim is None else MLP(
+            edge_in_dim, list(edge_fc_dims) + [edge_out_dim], dropout_p, use_batchnorm, is_classifier)
+
+    def forward(self, edge_feats=None, nodes_feats=None):
+        out_nodes = self.node_mlp(nodes_feats) if (self.node_mlp is not None and nodes_feats is not None) else nodes_feats
+        out_edges = self.edge_mlp(edge_feats) if (self.edge_mlp is not None and edge_feats is not None) else edge_feats
+        return out_edges, out_nodes
+
+
+class EdgeModel(nn.Module):
+    """Holds the edge-update MLP (reference models/mpn.py:59-69)."""
+
+    def __init__(self, edge_mlp):
+        super().__init__()
+        self.edge_mlp = edge_mlp
+
+
+class NodeModel(nn.Module):
+    """Holds the node-update MLP and the aggregation name (reference models/mpn.py:71-101)."""
+
+    def __init__(self, node_mlp, node_agg_fn: str):
+        super().__init__()
+        self.node_mlp = node_mlp
+        self.node_agg_fn = node_agg_fn
+
+
+class MetaLayer(nn.Module):
+    """One message-passing round = edge update then node update (reference models/mpn.py:10-57)."""
+
+    def __init__(self, edge_model=None, node_model=None):
+        super().__init__()
+        self.edge_model = edge_model
+        self.node_model = node_model
+
+    def __repr__(self):
+        return "{}(edge_model={}, node_model={})".format(self.__class__.__name__, self.edge_model, self.node_model)
+
+
+class MOTMPNet(nn.Module):
+    """`MOTMPNet(model_params, bb_encoder=None, arch=...)`, call sites main.py:96, main_training.py:211."""
+
+    def __init__(self, model_params: Dict, bb_encoder=None, arch: Optional[str] = None):
+        super().__init__()
+        self.node_cnn = bb_encoder          # stored, never used (reference models/mpn.py:163)
+        self.model_params = model_params
+        self.arch = arch
+        self.spec: MpnSpec = _config.resolve(model_params, arch)
+        ok, why = _config.check_supported(self.spec)
+        if not ok:
+            raise NotImplementedError("mtmc_mpn HIP path does not cover this GRAPH_NET_PARAMS: " + why)
+
+        enc_e = model_params["encoder_feats_dict"]["edges"]
+        enc_n = model_params["encoder_feats_dict"]["nodes"][arch]
+        # same in-place merge as the reference (models/mpn.py:169): callers may re-read the dict
+        enc_e.update(enc_n)
+        self.encoder = MLPGraphIndependent(**enc_e)
+        self.classifier = MLPGraphIndependent(**model_params["classifier_feats_dict"])
+        em, nm = model_params["edge_model_feats_dict"], model_params["node_model_feats_dict"]
+        s = self.spec
+        self.MPNet = MetaLayer(
+            edge_model=EdgeModel(MLP(s.upd_edge[0].in_dim, em["fc_dims"], em["dropout_p"], em["use_batchnorm"])),
+            node_model=NodeModel(MLP(s.upd_node[0].in_dim, nm["fc_dims"], nm["dropout_p"], nm["use_batchnorm"]),
+                                 s.agg))
+        self.reattach_initial_nodes = s.reattach_nodes
+        self.reattach_initial_edges = s.reattach_edges
+        self.num_enc_steps = s.num_enc_steps
+        self.num_class_steps = s.num_class_steps
+        self.check_indices = False          # True: synchronise and raise IndexError on out-of-range edge_index
+        self._engine = None
+
+    # -- the hot path -------------------------------------------------------------------
+    def forward(self, data):
+        from . import engine
+        if self._engine is None:
+            self._engine = engine.ForwardEngine(self)
+        x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr
+        logits, h = self._engine(x, edge_index, edge_attr, training=self.training)
+        return {"classified_edges": logits}, h
