@@ -1,0 +1,108 @@
+"""ctypes binding of the C ABI in include/mtmc_mpn.h (csrc/libmtmc_mpn.so, built for gfx950).
+
+The library is built in-tree (`python -m mtmc_mpn.build`, or `__graft_entry__.build()`).  If it is
+missing, loading fails loudly: there is no other implementation behind the module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+MAX_ENC_LAYERS = 8
+NODE_DIM, EDGE_DIM, MAX_CLASSES = 32, 4, 4
+AGG = {"sum": 0, "mean": 1, "max": 2}
+
+(PH_BEGIN, PH_EDGE_ENC, PH_NODE_ENC, PH_NODE_H0, PH_ROUND_PROJ, PH_ROUND_A, PH_ROUND_B, PH_ROUND_STAT,
+ PH_ROUND_C, PH_END) = range(10)
+
+E_ARG, E_WORKSPACE, E_HIP, E_ROWS = -1, -2, -3, -4
+
+_f32p = C.c_void_p
+
+
+class Layer(C.Structure):
+    _fields_ = [("weight", _f32p), ("bias", _f32p), ("gamma", _f32p), ("beta", _f32p),
+                ("in_dim", C.c_int32), ("out_dim", C.c_int32)]
+
+
+class Model(C.Structure):
+    _fields_ = [("n_enc_layers", C.c_int32), ("enc_node", Layer * MAX_ENC_LAYERS), ("enc_edge", Layer * 2),
+                ("upd_edge", Layer), ("upd_node", Layer), ("cls", Layer),
+                ("agg", C.c_int32), ("num_enc_steps", C.c_int32), ("num_class_steps", C.c_int32),
+                ("reattach_nodes", C.c_int32), ("reattach_edges", C.c_int32)]
+
+
+class Call(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("x_row_stride", C.c_int64), ("row", C.c_void_p), ("col", C.c_void_p),
+                ("idx_stride", C.c_int64), ("edge_attr", C.c_void_p), ("n_nodes", C.c_int64), ("n_edges", C.c_int64),
+                ("n_edges_total", C.c_int64), ("node_lo", C.c_int64), ("node_hi", C.c_int64),
+                ("logits", C.c_void_p), ("h_out", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t), ("training", C.c_int32), ("flags", C.c_int32),
+                ("seed", C.c_uint64), ("stream", C.c_void_p)]
+
+
+class WsLayout(C.Structure):
+    _fields_ = [("total_bytes", C.c_size_t), ("zero_bytes", C.c_size_t), ("flags_off", C.c_size_t),
+                ("stat_attr_off", C.c_size_t), ("stat_enc2_off", C.c_size_t), ("stat_enc_node_off", C.c_size_t),
+                ("stat_round_off", C.c_size_t), ("deg_off", C.c_size_t), ("seg_off", C.c_size_t),
+                ("h0_off", C.c_size_t), ("h_acc_off", C.c_size_t * 2)]
+
+
+# doubles per statistics block (csrc/common.h)
+STAT_ATTR, STAT_ENC2, STAT_ROUND = 6, 16, 88
+ROUND_Z1, ROUND_M1, ROUND_Z2 = (0, 8), (8, 22), (22, 86)     # [begin, end) inside a round block
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmtmc_mpn.so")
+EXPORTS = ["mtmc_mpn_abi_version", "mtmc_mpn_last_error", "mtmc_mpn_workspace_bytes", "mtmc_mpn_workspace_layout",
+           "mtmc_mpn_forward", "mtmc_mpn_run_phase", "mtmc_scatter_add", "mtmc_scatter_mean", "mtmc_scatter_max",
+           "mtmc_mlp_layer_forward"]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen the HIP library (after torch, so both share torch's libamdhip64) and type its entry points."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"mtmc_mpn: HIP extension not built ({LIB_PATH} missing); run `python -m mtmc_mpn.build` "
+                           "-- there is no fallback implementation")
+    import torch  # noqa: F401  (loads the ROCm runtime the library links against)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    lib.mtmc_mpn_abi_version.restype = C.c_int32
+    lib.mtmc_mpn_last_error.restype = C.c_char_p
+    lib.mtmc_mpn_workspace_bytes.restype = C.c_size_t
+    lib.mtmc_mpn_workspace_bytes.argtypes = [C.POINTER(Model), C.c_int64, C.c_int64]
+    lib.mtmc_mpn_workspace_layout.restype = C.c_int32
+    lib.mtmc_mpn_workspace_layout.argtypes = [C.POINTER(Model), C.c_int64, C.c_int64, C.POINTER(WsLayout)]
+    lib.mtmc_mpn_forward.restype = C.c_int32
+    lib.mtmc_mpn_forward.argtypes = [C.POINTER(Model), C.POINTER(Call)]
+    lib.mtmc_mpn_run_phase.restype = C.c_int32
+    lib.mtmc_mpn_run_phase.argtypes = [C.POINTER(Model), C.POINTER(Call), C.c_int32, C.c_int32]
+    for name in ("mtmc_scatter_add",):
+        getattr(lib, name).restype = C.c_int32
+        getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.mtmc_scatter_mean.restype = C.c_int32
+    lib.mtmc_scatter_mean.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]
+    lib.mtmc_scatter_max.restype = C.c_int32
+    lib.mtmc_scatter_max.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]
+    lib.mtmc_mlp_layer_forward.restype = C.c_int32
+    lib.mtmc_mlp_layer_forward.argtypes = [C.POINTER(Layer), C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                           C.c_void_p]
+    if lib.mtmc_mpn_abi_version() != 1:
+        raise RuntimeError("mtmc_mpn: ABI version mismatch between _lib.py and libmtmc_mpn.so")
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    """Map a negative return code to the exception the reference's path would raise."""
+    if rc == 0:
+        return
+    msg = load().mtmc_mpn_last_error().decode()
+    if rc == E_ROWS:
+        raise ValueError(msg)
+    raise RuntimeError(f"mtmc_mpn: {msg} (code {rc})")

@@ -1,0 +1,143 @@
+// Shared device helpers for the gfx950 message-passing kernels.
+// gfx950 only: 64-wide wavefronts are hard-coded.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MTMC_BN_EPS 1e-5
+
+namespace mtmc {
+
+constexpr int kWave = 64;
+constexpr int kH = 32;    // node state width
+constexpr int kHe = 4;    // edge state width
+
+// ---- statistics layout (doubles) -------------------------------------------------------------
+// Second-moment matrices are symmetric and stored packed (upper triangle, row-major):
+//   tri(n,i,j), i<=j  ->  i*n - i*(i-1)/2 + (j-i)
+// attr moments : m1[2] | m2 packed[3]                                   (6 doubles reserved)
+// enc2 moments : m1[4] | m2 packed[10]                                  (16 reserved)
+// round stats  : z1 sum[4] | z1 sumsq[4] | e' m1[4] | e' m2 packed[10] | z2 sum[32] | z2 sumsq[32]
+constexpr int kStatAttr = 6;
+constexpr int kStatEnc2 = 16;
+constexpr int kRoundZ1 = 0, kRoundM1 = 8, kRoundM2 = 12, kRoundZ2 = 22, kRoundStride = 88;
+
+__host__ __device__ __forceinline__ constexpr int tri(int n, int i, int j) { return i * n - i * (i - 1) / 2 + (j - i); }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  return v;   // lane 0 holds the total
+}
+
+// Block-wide sum of NV per-thread doubles; result atomically added to dst[0..NV).
+// smem: at least NV * (blockDim.x/64) doubles.  All threads must call.
+template <int NV>
+__device__ __forceinline__ void block_atomic_add(const double (&v)[NV], double* dst, double* smem) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double s = wave_sum(v[i]);
+    if (lane == 0) smem[wid * NV + i] = s;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NV; i += blockDim.x) {
+    double s = 0;
+    for (int w = 0; w < nw; ++w) s += smem[w * NV + i];
+    unsafeAtomicAdd(dst + i, s);
+  }
+  __syncthreads();
+}
+
+// BatchNorm (batch statistics) as y = s*z + t from fp64 (sum, sumsq) over `count` rows.
+__device__ __forceinline__ void bn_affine(double sum, double sumsq, double count, float gamma, float beta,
+                                          float& s, float& t) {
+  const double mean = sum / count;
+  double var = sumsq / count - mean * mean;
+  var = var < 0 ? 0 : var;
+  const double sd = (double)gamma / sqrt(var + MTMC_BN_EPS);
+  s = (float)sd;
+  t = (float)((double)beta - mean * sd);
+}
+
+// Small per-launch parameter blocks, read through uniform (scalar) loads.
+struct EdgeEncParams {      // encoder.edge_mlp: in(1|2) -> 4 -> 4
+  const float* w1; const float* b1; const float* g1; const float* bt1;
+  const float* w2; const float* b2; const float* g2; const float* bt2;
+  const double* stat_attr;  // f64[kStatAttr]
+  const double* stat_enc2;  // f64[kStatEnc2]
+  int fe;                   // edge_in_dim (1 or 2)
+};
+
+// Affine coefficients of the two edge-encoder BatchNorms, derived from moments:
+//   layer 1 pre-activation z = W1 a + b1 : E[z_k] = W1_k.m1 + b1_k, E[z_k^2] = W1_k M2 W1_k^T + 2 b1_k W1_k.m1 + b1_k^2
+struct EdgeEncAffine { float s1[4], t1[4], s2[4], t2[4]; };
+
+// quadratic form w^T M w for a packed symmetric M
+__device__ __forceinline__ double quad_form(const float* w, int n, const double* m2) {
+  double q = 0;
+  for (int i = 0; i < n; ++i) {
+    q += (double)w[i] * (double)w[i] * m2[tri(n, i, i)];
+    for (int j = i + 1; j < n; ++j) q += 2.0 * (double)w[i] * (double)w[j] * m2[tri(n, i, j)];
+  }
+  return q;
+}
+
+__device__ __forceinline__ void moments_affine(const float* w, int in_dim, float bias, const double* m1,
+                                               const double* m2, double count, float gamma, float beta,
+                                               float& s, float& t) {
+  double wm1 = 0;
+  for (int i = 0; i < in_dim; ++i) wm1 += (double)w[i] * m1[i];
+  const double q = quad_form(w, in_dim, m2);
+  const double b = bias;
+  const double sum = wm1 + b * count;                       // sum over rows of z
+  const double sumsq = q + 2.0 * b * wm1 + b * b * count;   // sum over rows of z^2
+  bn_affine(sum, sumsq, count, gamma, beta, s, t);
+}
+
+// Computed by threads 0..3 of a block into shared memory; `which`: 1 = layer-1 only, 2 = both.
+__device__ __forceinline__ void edge_enc_affine_to_smem(const EdgeEncParams& p, double count, int which,
+                                                        EdgeEncAffine* out) {
+  const int k = threadIdx.x;
+  if (k < 4) {
+    moments_affine(p.w1 + k * p.fe, p.fe, p.b1[k], p.stat_attr, p.stat_attr + 2, count, p.g1[k], p.bt1[k],
+                   out->s1[k], out->t1[k]);
+    if (which >= 2)
+      moments_affine(p.w2 + k * 4, 4, p.b2[k], p.stat_enc2, p.stat_enc2 + 4, count, p.g2[k], p.bt2[k],
+                     out->s2[k], out->t2[k]);
+  }
+}
+
+// u = relu(bn1(W1 a + b1)) : hidden layer of the edge encoder
+__device__ __forceinline__ void edge_enc_hidden(const EdgeEncParams& p, const EdgeEncAffine& af, float a0, float a1,
+                                                float (&u)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float z = p.b1[k] + p.w1[k * p.fe] * a0;
+    if (p.fe > 1) z = fmaf(p.w1[k * p.fe + 1], a1, z);
+    u[k] = fmaxf(fmaf(z, af.s1[k], af.t1[k]), 0.f);
+  }
+}
+
+// e0 = relu(bn2(W2 u + b2)) : output of the edge encoder
+__device__ __forceinline__ void edge_enc_out(const EdgeEncParams& p, const EdgeEncAffine& af, const float (&u)[4],
+                                             float (&e)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float z = p.b2[k];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) z = fmaf(p.w2[k * 4 + j], u[j], z);
+    e[k] = fmaxf(fmaf(z, af.s2[k], af.t2[k]), 0.f);
+  }
+}
+
+__device__ __forceinline__ void load_attr(const float* attr, int fe, int64_t e, float& a0, float& a1) {
+  if (fe == 2) {
+    const float2 v = reinterpret_cast<const float2*>(attr)[e];
+    a0 = v.x; a1 = v.y;
+  } else {
+    a0 = attr[e]; a1 = 0.f;
+  }
+}
+
+}  // namespace mtmc

@@ -1,0 +1,351 @@
+// Per-edge passes of the message-passing network on gfx950 (MI355X).
+//
+// These are the HBM-bound kernels: each streams the edge list once, gathers 16-byte per-node
+// projections instead of the reference's 128-byte node rows (W.[h[row]|h[col]|e] = Pr[row]+Pc[col]+We.e),
+// and never materialises the [E,68] / [E,36] / [E,32] intermediates of the reference
+// (reference models/mpn.py:68, :97-98).  BatchNorm batch statistics are accumulated in fp64.
+//
+//   prep_kernel        int64 strided edge_index -> int32 row/col, out-degree, moments of edge_attr
+//   enc2_kernel        moments of the edge-encoder hidden activations
+//   pass_a_kernel      statistics of z1 = We.[h[row]|h[col]|e] + be               (EdgeModel, mpn.py:67-69)
+//   pass_b_kernel      e' = relu(bn(z1)) stored; moments of e'; per-node segment sums of e'
+//   pass_c_kernel      m = relu(bn(Wn.[h[row]|e'] + bn)); h' = agg_row(m); logits  (NodeModel, mpn.py:97-99)
+//   classify_e0_kernel logits of the encoded edges when L == 0                      (mpn.py:295-297)
+#include "kernels.h"
+
+namespace mtmc {
+
+// ------------------------------------------------------------------------------------------------
+// prep
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prep_kernel(PrepParams p) {
+  __shared__ double red[5 * 4];
+  double acc[5] = {0, 0, 0, 0, 0};
+  const int lane = threadIdx.x & 63;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  // whole waves iterate together so that the run-length logic sees 64 consecutive edges
+  const int64_t e_end = ((p.n_edges + 63) / 64) * 64;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < e_end; e += nthreads) {
+    const bool active = e < p.n_edges;
+    int64_t r64 = 0, c64 = 0;
+    if (active) {
+      r64 = p.row[e * p.idx_stride];
+      c64 = p.col[e * p.idx_stride];
+      if (r64 < 0 || r64 >= p.n_nodes || c64 < 0 || c64 >= p.n_nodes) {
+        p.flags[1] = 1;                                   // out of range: clamp, report
+        r64 = r64 < 0 ? 0 : (r64 >= p.n_nodes ? p.n_nodes - 1 : r64);
+        c64 = c64 < 0 ? 0 : (c64 >= p.n_nodes ? p.n_nodes - 1 : c64);
+      }
+      p.row32[e] = (int)r64;
+      p.col32[e] = (int)c64;
+      float a0, a1;
+      load_attr(p.attr, p.fe, e, a0, a1);
+      acc[0] += a0; acc[1] += a1;
+      acc[2] += (double)a0 * a0; acc[3] += (double)a0 * a1; acc[4] += (double)a1 * a1;
+    }
+    const int r = active ? (int)r64 : -1;
+    int prev = __shfl_up(r, 1, 64);
+    if (lane == 0) prev = (active && e > 0) ? (int)p.row[(e - 1) * p.idx_stride] : r;
+    if (active && prev > r) p.flags[0] = 1;               // rows not globally non-decreasing
+    // out-degree: one atomic per run of equal rows inside the wave
+    const bool head = active && (lane == 0 || prev != r);
+    const unsigned long long heads = __ballot(head);
+    const int n_active = __popcll(__ballot(active));
+    if (head) {
+      const unsigned long long above = (lane == 63) ? 0ull : (heads >> (lane + 1));
+      const int len = above ? (__ffsll((long long)above)) : (n_active - lane);
+      atomicAdd(p.deg + r, len);
+    }
+  }
+  block_atomic_add<5>(acc, p.stat_attr, red);
+}
+
+// ------------------------------------------------------------------------------------------------
+// edge encoder, hidden-layer moments
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void enc2_kernel(EdgeEncParams enc, const float* attr, int64_t n_edges,
+                                                   double e_total, double* stat_enc2) {
+  __shared__ EdgeEncAffine af;
+  __shared__ double red[14 * 4];
+  edge_enc_affine_to_smem(enc, e_total, 1, &af);
+  __syncthreads();
+  double acc[14];
+#pragma unroll
+  for (int i = 0; i < 14; ++i) acc[i] = 0;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += nthreads) {
+    float a0, a1, u[4];
+    load_attr(attr, enc.fe, e, a0, a1);
+    edge_enc_hidden(enc, af, a0, a1, u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[i] += u[i];
+#pragma unroll
+      for (int j = i; j < 4; ++j) acc[4 + tri(4, i, j)] += (double)u[i] * u[j];
+    }
+  }
+  block_atomic_add<14>(acc, stat_enc2, red);
+}
+
+// ------------------------------------------------------------------------------------------------
+// z1 of one edge: Pr[row] + Pc[col] + We_e . e_in + be
+// ------------------------------------------------------------------------------------------------
+struct EdgeUpdWeights { float w[4][8]; float b[4]; };
+
+__device__ __forceinline__ void load_edge_upd_weights(const RoundParams& p, EdgeUpdWeights& w) {
+  const int nin = p.reattach_edges ? 8 : 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    w.b[k] = p.ue_b[k];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w.w[k][j] = j < nin ? p.ue_w[k * p.ue_ld + p.ue_eoff + j] : 0.f;
+  }
+}
+
+__device__ __forceinline__ void edge_z1(const RoundParams& p, const EdgeEncAffine& af, const EdgeUpdWeights& w,
+                                        int64_t e, int& r, float (&z)[4]) {
+  r = p.row32[e];
+  const int c = p.col32[e];
+  const float4 pr = *reinterpret_cast<const float4*>(p.P + (int64_t)r * 8);
+  const float4 pc = *reinterpret_cast<const float4*>(p.P + (int64_t)c * 8 + 4);
+  float e0[4] = {0, 0, 0, 0}, ep[4];
+  if (p.first_round || p.reattach_edges) {
+    float a0, a1, u[4];
+    load_attr(p.attr, p.enc.fe, e, a0, a1);
+    edge_enc_hidden(p.enc, af, a0, a1, u);
+    edge_enc_out(p.enc, af, u, e0);
+  }
+  if (p.first_round) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ep[j] = e0[j];
+  } else {
+    const float4 v = reinterpret_cast<const float4*>(p.e_buf)[e];
+    ep[0] = v.x; ep[1] = v.y; ep[2] = v.z; ep[3] = v.w;
+  }
+  const float prv[4] = {pr.x, pr.y, pr.z, pr.w}, pcv[4] = {pc.x, pc.y, pc.z, pc.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float acc = prv[k] + pcv[k] + w.b[k];
+    if (p.reattach_edges) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = fmaf(w.w[k][j], e0[j], acc);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = fmaf(w.w[k][4 + j], ep[j], acc);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = fmaf(w.w[k][j], ep[j], acc);
+    }
+    z[k] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void pass_a_kernel(RoundParams p) {
+  __shared__ EdgeEncAffine af;
+  __shared__ double red[8 * 4];
+  if (p.first_round || p.reattach_edges) edge_enc_affine_to_smem(p.enc, p.e_total, 2, &af);
+  __syncthreads();
+  EdgeUpdWeights w;
+  load_edge_upd_weights(p, w);
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < p.n_edges; e += nthreads) {
+    int r;
+    float z[4];
+    edge_z1(p, af, w, e, r, z);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      acc[k] += z[k];
+      acc[4 + k] += (double)z[k] * z[k];
+    }
+  }
+  block_atomic_add<8>(acc, p.stats + kRoundZ1, red);
+}
+
+__global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
+  __shared__ EdgeEncAffine af;
+  __shared__ float s1[4], t1[4];
+  __shared__ double red[14 * 4];
+  if (p.first_round || p.reattach_edges) edge_enc_affine_to_smem(p.enc, p.e_total, 2, &af);
+  if (threadIdx.x < 4) {
+    const int k = threadIdx.x;
+    bn_affine(p.stats[kRoundZ1 + k], p.stats[kRoundZ1 + 4 + k], p.e_total, p.ue_g[k], p.ue_bt[k], s1[k], t1[k]);
+  }
+  __syncthreads();
+  EdgeUpdWeights w;
+  load_edge_upd_weights(p, w);
+  double acc[14];
+#pragma unroll
+  for (int i = 0; i < 14; ++i) acc[i] = 0;
+  const int lane = threadIdx.x & 63;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  const int64_t e_end = ((p.n_edges + 63) / 64) * 64;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < e_end; e += nthreads) {
+    const bool active = e < p.n_edges;
+    int r = -1;
+    float v[4] = {0, 0, 0, 0};
+    if (active) {
+      float z[4];
+      edge_z1(p, af, w, e, r, z);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = fmaxf(fmaf(z[k], s1[k], t1[k]), 0.f);
+      reinterpret_cast<float4*>(p.e_buf)[e] = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[i] += v[i];
+#pragma unroll
+        for (int j = i; j < 4; ++j) acc[4 + tri(4, i, j)] += (double)v[i] * v[j];
+      }
+    }
+    // per-node segment sums S[row] += e': segmented inclusive scan over the wave (any row order),
+    // then one fp64 atomic per run and channel
+    const int prev = __shfl_up(r, 1, 64);
+    int flag = (lane == 0 || prev != r) ? 1 : 0;
+    const int next_head = __shfl_down(flag, 1, 64);
+    const bool tail = active && (lane == 63 || next_head != 0 || e + 1 >= p.n_edges);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int f_up = __shfl_up(flag, off, 64);
+      float u[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) u[k] = __shfl_up(v[k], off, 64);
+      if (lane >= off && !flag) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += u[k];
+        flag = f_up;
+      }
+    }
+    if (tail) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) unsafeAtomicAdd(p.seg + (int64_t)r * 4 + k, (double)v[k]);
+    }
+  }
+  block_atomic_add<14>(acc, p.stats + kRoundM1, red);
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass C: 32 lanes = 32 channels; every half-wave walks 32 consecutive edges of the block's tile
+// ------------------------------------------------------------------------------------------------
+constexpr int kTileC = 256;
+
+__device__ __forceinline__ void flush_node(const RoundParams& p, int node, int k, float acc) {
+  float* dst = p.h_acc + (int64_t)node * kH + k;
+  if (p.agg == 2) {
+    atomicMax(reinterpret_cast<int*>(dst), __float_as_int(acc));   // values are >= 0: int order == float order
+  } else {
+    unsafeAtomicAdd(dst, acc);
+  }
+}
+
+__global__ __launch_bounds__(256) void pass_c_kernel(RoundParams p) {
+  __shared__ float4 tile_e[kTileC];
+  __shared__ int tile_row[kTileC];
+  const int k = threadIdx.x & 31;          // channel
+  const int hw = threadIdx.x >> 5;         // half-wave 0..7
+  // BatchNorm affine of channel k of z2 from the moment statistics (node_stat_kernel + pass B)
+  float sk, tk;
+  {
+    const float* a = p.un_w + k * p.un_ld + p.un_eoff;
+    const double quad = quad_form(a, 4, p.stats + kRoundM2);
+    bn_affine(p.stats[kRoundZ2 + k], p.stats[kRoundZ2 + 32 + k] + quad, p.e_total, p.un_g[k], p.un_bt[k], sk, tk);
+  }
+  float a4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a4[j] = sk * p.un_w[k * p.un_ld + p.un_eoff + j];
+  const float cb = fmaf(sk, p.un_b[k], tk);
+
+  const int64_t n_tiles = (p.n_edges + kTileC - 1) / kTileC;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t base = tile * kTileC;
+    const int64_t e = base + threadIdx.x;
+    float4 ev = make_float4(0, 0, 0, 0);
+    if (e < p.n_edges) {
+      ev = reinterpret_cast<const float4*>(p.e_buf)[e];
+      tile_row[threadIdx.x] = p.row32[e];
+      if (p.logits) {                                         // classifier on this edge (mpn.py:291-292)
+        float lg[MTMC_MAX_CLASSES];
+        for (int c = 0; c < p.n_classes; ++c) {
+          const float* w = p.cls_w + c * 4;
+          lg[c] = fmaf(w[3], ev.w, fmaf(w[2], ev.z, fmaf(w[1], ev.y, fmaf(w[0], ev.x, p.cls_b[c]))));
+        }
+        if (p.n_classes == 2) {
+          reinterpret_cast<float2*>(p.logits)[e] = make_float2(lg[0], lg[1]);
+        } else {
+          for (int c = 0; c < p.n_classes; ++c) p.logits[e * p.n_classes + c] = lg[c];
+        }
+      }
+    }
+    tile_e[threadIdx.x] = ev;
+    __syncthreads();
+    const int n_here = (int)min((int64_t)32, p.n_edges - (base + hw * 32));   // may be <= 0
+    int cur = -1;
+    float acc = 0.f, c0 = 0.f;
+    for (int j = 0; j < n_here; ++j) {
+      const int r = tile_row[hw * 32 + j];
+      const float4 v = tile_e[hw * 32 + j];
+      if (r != cur) {
+        if (cur >= 0) flush_node(p, cur, k, acc);
+        cur = r;
+        acc = 0.f;
+        c0 = fmaf(sk, p.Q[(int64_t)r * kH + k], cb);
+      }
+      const float m = fmaxf(fmaf(a4[3], v.w, fmaf(a4[2], v.z, fmaf(a4[1], v.y, fmaf(a4[0], v.x, c0)))), 0.f);
+      acc = (p.agg == 2) ? fmaxf(acc, m) : acc + m;
+    }
+    if (cur >= 0) flush_node(p, cur, k, acc);
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void classify_e0_kernel(EdgeEncParams enc, const float* attr, int64_t n_edges,
+                                                          double e_total, const float* cls_w, const float* cls_b,
+                                                          int n_classes, float* logits) {
+  __shared__ EdgeEncAffine af;
+  edge_enc_affine_to_smem(enc, e_total, 2, &af);
+  __syncthreads();
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += nthreads) {
+    float a0, a1, u[4], e0[4];
+    load_attr(attr, enc.fe, e, a0, a1);
+    edge_enc_hidden(enc, af, a0, a1, u);
+    edge_enc_out(enc, af, u, e0);
+    for (int c = 0; c < n_classes; ++c) {
+      float z = cls_b[c];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) z = fmaf(cls_w[c * 4 + j], e0[j], z);
+      logits[e * n_classes + c] = z;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------
+static inline int edge_grid(int64_t n_edges, int per_block) {
+  const int64_t blocks = (n_edges + per_block - 1) / per_block;
+  return (int)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
+}
+
+void launch_prep(const PrepParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(prep_kernel, dim3(edge_grid(p.n_edges, 256)), dim3(256), 0, s, p);
+}
+void launch_enc2(const EdgeEncParams& enc, const float* attr, int64_t n_edges, double e_total, double* stat_enc2,
+                 hipStream_t s) {
+  hipLaunchKernelGGL(enc2_kernel, dim3(edge_grid(n_edges, 256)), dim3(256), 0, s, enc, attr, n_edges, e_total,
+                     stat_enc2);
+}
+void launch_pass_a(const RoundParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(pass_a_kernel, dim3(edge_grid(p.n_edges, 256)), dim3(256), 0, s, p);
+}
+void launch_pass_b(const RoundParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(pass_b_kernel, dim3(edge_grid(p.n_edges, 256)), dim3(256), 0, s, p);
+}
+void launch_pass_c(const RoundParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(pass_c_kernel, dim3(edge_grid(p.n_edges, kTileC)), dim3(256), 0, s, p);
+}
+void launch_classify_e0(const EdgeEncParams& enc, const float* attr, int64_t n_edges, double e_total,
+                        const float* cls_w, const float* cls_b, int n_classes, float* logits, hipStream_t s) {
+  hipLaunchKernelGGL(classify_e0_kernel, dim3(edge_grid(n_edges, 256)), dim3(256), 0, s, enc, attr, n_edges, e_total,
+                     cls_w, cls_b, n_classes, logits);
+}
+
+}  // namespace mtmc

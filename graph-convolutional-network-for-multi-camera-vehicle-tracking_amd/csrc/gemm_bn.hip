@@ -1,0 +1,219 @@
+// Node-encoder layer on the gfx950 matrix cores:   Y = act(A) . W^T + b,   column statistics of Y fused.
+//
+// One layer of reference MLP.forward (models/mlp.py:11-33) for the node encoder 2048->1024->512->128->32
+// (models/mpn.py:131).  The reference runs Linear, BatchNorm1d (batch statistics), ReLU as three passes
+// over [N, d]; here
+//   * the previous layer's BatchNorm+ReLU is applied while its raw output is staged into LDS
+//     (act(a) = relu(s_k a + t_k), s/t from that layer's fp64 column statistics), and
+//   * this layer's column sum / sum of squares are reduced in fp64 in the epilogue,
+// so every [N, d] activation is written once and read once.
+//
+// Arithmetic: exact fp32 on v_mfma_f32_32x32x2_f32 (bit-for-bit a k-ordered fmaf chain; there is no
+// reduced-precision f32 path on gfx950 and BatchNorm amplifies input error).
+// Tiling: 256 threads = 2x2 waves, each wave TM x TN MFMA tiles of 32x32, BK = 32.  A and W tiles are both
+// k-contiguous in HBM and in LDS (rows padded to 36 floats => conflict-free ds_read_b128); a lane's
+// 16-byte read feeds four consecutive MFMAs (lane half h supplies k = 8*kk + 4*h + j in step j, for A and
+// W alike, so the k-permutation cancels).  Register-staged double buffering: the next k-tile's global loads
+// are in flight while the current one is multiplied.
+#include "kernels.h"
+
+namespace mtmc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_bn_kernel(GemmParams p, int tiles_m, int tiles_n) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int A4 = BM / 32, B4 = BN / 32;          // float4 loads per thread per k-tile
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                                   // [BM][LDK]
+  float* Bs = smem + BM * LDK;                        // [BN][LDK]
+  float* s_in = Bs + BN * LDK;                        // [K]
+  float* t_in = s_in + p.K;                           // [K]
+
+  // XCD-aware tile order: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch); give each XCD
+  // whole row panels so the A panel is re-read from its own L2 by the panel's column tiles.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tm_idx = (slot / tiles_n) * 8 + xcd, tn_idx = slot % tiles_n;
+  if (tm_idx >= tiles_m) return;
+  const int64_t m0 = (int64_t)tm_idx * BM;
+  const int n0 = tn_idx * BN;
+
+  const bool act = p.stats_in != nullptr;
+  if (act) {
+    for (int kk = threadIdx.x; kk < p.K; kk += 256)
+      bn_affine(p.stats_in[kk], p.stats_in[p.K + kk], p.count, p.gamma_in[kk], p.beta_in[kk], s_in[kk], t_in[kk]);
+  }
+
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+
+  float4 ra[A4], rb[B4];
+  auto load_tiles = [&](int kt) {
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < A4; ++i) {
+      const int f = threadIdx.x + i * 256, r = f >> 3, c4 = f & 7;
+      const int64_t row = m0 + r;
+      ra[i] = row < p.M ? *reinterpret_cast<const float4*>(p.A + row * p.lda + k0 + c4 * 4)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < B4; ++i) {
+      const int f = threadIdx.x + i * 256, r = f >> 3, c4 = f & 7;
+      const int n = n0 + r;
+      rb[i] = n < p.Nout ? *reinterpret_cast<const float4*>(p.W + (int64_t)n * p.K + k0 + c4 * 4)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_tiles = [&](int kt) {
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < A4; ++i) {
+      const int f = threadIdx.x + i * 256, r = f >> 3, c4 = f & 7;
+      float4 v = ra[i];
+      if (act) {
+        const float4 s = *reinterpret_cast<const float4*>(s_in + k0 + c4 * 4);
+        const float4 t = *reinterpret_cast<const float4*>(t_in + k0 + c4 * 4);
+        v.x = fmaxf(fmaf(v.x, s.x, t.x), 0.f);
+        v.y = fmaxf(fmaf(v.y, s.y, t.y), 0.f);
+        v.z = fmaxf(fmaf(v.z, s.z, t.z), 0.f);
+        v.w = fmaxf(fmaf(v.w, s.w, t.w), 0.f);
+      }
+      *reinterpret_cast<float4*>(As + r * LDK + c4 * 4) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B4; ++i) {
+      const int f = threadIdx.x + i * 256, r = f >> 3, c4 = f & 7;
+      *reinterpret_cast<float4*>(Bs + r * LDK + c4 * 4) = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK;
+  load_tiles(0);
+  const int a_off = (wm * TM * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
+  const int b_off = (wn * TN * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();                 // s_in/t_in ready (kt == 0); previous tile fully consumed
+    store_tiles(kt);
+    __syncthreads();
+    if (kt + 1 < nk) load_tiles(kt + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      float4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(As + a_off + i * 32 * LDK + kk * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(Bs + b_off + j * 32 * LDK + kk * 8);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+
+  // epilogue: + bias, store raw Y, fp64 column statistics
+  __syncthreads();
+  double* colred = reinterpret_cast<double*>(smem);   // [2 (wm)][2 (sum,sq)][BN]
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int cl = wn * TN * 32 + j * 32 + (lane & 31);
+    const int col = n0 + cl;
+    const float bias = col < p.Nout ? p.bias[col] : 0.f;
+    double cs = 0, cq = 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < p.M && col < p.Nout) {
+          const float y = acc[i][j][r] + bias;
+          p.Y[row * p.ldy + col] = y;
+          cs += y;
+          cq += (double)y * y;
+        }
+      }
+    }
+    cs += __shfl_xor(cs, 32, 64);
+    cq += __shfl_xor(cq, 32, 64);
+    if (lane < 32) {
+      colred[(wm * 2 + 0) * BN + cl] = cs;
+      colred[(wm * 2 + 1) * BN + cl] = cq;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * BN; i += 256) {
+    const int which = i / BN, cl = i % BN, col = n0 + cl;
+    if (col < p.Nout && p.stats_out)
+      unsafeAtomicAdd(p.stats_out + which * p.Nout + col, colred[(0 * 2 + which) * BN + cl] + colred[(1 * 2 + which) * BN + cl]);
+  }
+}
+
+// Generic path for shapes the MFMA kernel does not take (K not a multiple of 32, unaligned rows): the small
+// edge-side layers when MLP.forward is used as a stand-alone op.  One thread per output element.
+__global__ __launch_bounds__(256) void linear_generic_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  double* cs = reinterpret_cast<double*>(smem);       // [2][Nout]
+  for (int i = threadIdx.x; i < 2 * p.Nout; i += 256) cs[i] = 0.0;
+  __syncthreads();
+  const int64_t total = p.M * p.Nout, stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / p.Nout;
+    const int c = (int)(i % p.Nout);
+    float acc = p.bias[c];
+    for (int k = 0; k < p.K; ++k) acc = fmaf(p.A[r * p.lda + k], p.W[(int64_t)c * p.K + k], acc);
+    p.Y[r * p.ldy + c] = acc;
+    if (p.stats_out) {
+      atomicAdd(&cs[c], (double)acc);
+      atomicAdd(&cs[p.Nout + c], (double)acc * acc);
+    }
+  }
+  __syncthreads();
+  if (p.stats_out)
+    for (int i = threadIdx.x; i < 2 * p.Nout; i += 256) unsafeAtomicAdd(p.stats_out + i, cs[i]);
+}
+
+template <int TM, int TN>
+static void launch_cfg(const GemmParams& p, hipStream_t s) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  const int tiles_m = (int)((p.M + BM - 1) / BM), tiles_n = (p.Nout + BN - 1) / BN;
+  const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
+  size_t lds = (size_t)(BM + BN) * LDK * sizeof(float) + (size_t)2 * p.K * sizeof(float);
+  const size_t epi = (size_t)4 * BN * sizeof(double);
+  if (lds < epi) lds = epi;
+  hipLaunchKernelGGL((gemm_bn_kernel<TM, TN>), dim3(grid), dim3(256), lds, s, p, tiles_m, tiles_n);
+}
+
+int launch_gemm_bn(const GemmParams& p, hipStream_t s) {
+  if (p.M < 1 || p.Nout < 1 || p.K < 1) return MTMC_E_ARG;
+  if (p.K % BK != 0 || p.K > 6144 || (p.lda % 4) != 0 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) {
+    if (p.stats_in != nullptr || p.Nout > 2048) return MTMC_E_ARG;
+    const int64_t blocks = (p.M * p.Nout + 255) / 256;
+    hipLaunchKernelGGL(linear_generic_kernel, dim3((int)(blocks > 2048 ? 2048 : blocks)), dim3(256),
+                       (size_t)2 * p.Nout * sizeof(double), s, p);
+    return MTMC_OK;
+  }
+  // big problems: 128x128 tiles; small ones (few row panels): 64x64 tiles to put more blocks on the chip
+  const int64_t big_tiles = ((p.M + 127) / 128) * ((p.Nout + 127) / 128);
+  if (big_tiles >= 512 && p.Nout >= 128) launch_cfg<2, 2>(p, s);
+  else launch_cfg<1, 1>(p, s);
+  return MTMC_OK;
+}
+
+}  // namespace mtmc

@@ -1,0 +1,86 @@
+// Internal launch interface between the C-ABI layer (api.hip) and the kernel translation units.
+#pragma once
+#include "../../include/mtmc_mpn.h"
+#include "common.h"
+
+namespace mtmc {
+
+struct PrepParams {
+  const int64_t* row; const int64_t* col; int64_t idx_stride;
+  const float* attr; int fe;
+  int64_t n_edges; int64_t n_nodes;
+  int* row32; int* col32; int* deg; int* flags;
+  double* stat_attr;
+};
+
+// Everything one message-passing round needs (passes A, B, C).
+struct RoundParams {
+  const int* row32; const int* col32; const float* attr; float* e_buf;
+  const float* P;            // [N][8]  Pr | Pc
+  const float* Q;            // [N][32]
+  const float* ue_w; const float* ue_b; const float* ue_g; const float* ue_bt; int ue_ld; int ue_eoff;
+  const float* un_w; const float* un_b; const float* un_g; const float* un_bt; int un_ld; int un_eoff;
+  const float* cls_w; const float* cls_b; int n_classes;
+  double* stats;             // this round's kRoundStride doubles
+  double* seg;               // [N][4]
+  float* h_acc;              // [N][32] aggregation target (pre-zeroed)
+  float* logits;             // this round's [E][C] output or nullptr
+  int64_t n_edges; double e_total;
+  int first_round; int reattach_edges; int agg;
+  EdgeEncParams enc;
+};
+
+struct NodeProjParams {
+  const float* h_src;        // [N][32]
+  const float* h0;           // [N][32] (reattach_nodes) or nullptr
+  const int* deg;            // mean aggregation: scale h_src rows by 1/max(deg,1); else nullptr
+  const float* ue_w; int ue_ld;
+  const float* un_w; int un_ld;
+  int hn;                    // 32 or 64: width of [h0 | h]
+  float* P; float* Q;
+  float* zero_buf;           // [N][32] cleared for the coming aggregation, or nullptr
+  int64_t n_nodes;
+};
+
+struct NodeStatParams {
+  const float* Q; const int* deg; double* seg;
+  const float* un_w; const float* un_b; int un_ld; int un_eoff;
+  double* stats;             // this round's block; z2 sums at kRoundZ2
+  int64_t n_nodes;
+};
+
+struct GemmParams {
+  const float* A; int64_t lda;       // [M][K] activations (raw pre-BN outputs of the previous layer, or x)
+  const float* W;                    // [Nout][K]
+  const float* bias;                 // [Nout]
+  float* Y; int64_t ldy;             // [M][Nout] raw outputs (pre-BN)
+  const double* stats_in;            // f64[2*K] column sum / sumsq of A's producer, or nullptr (layer 0)
+  const float* gamma_in; const float* beta_in;
+  double count;                      // BatchNorm row count (global N)
+  double* stats_out;                 // f64[2*Nout], accumulated atomically
+  int64_t M; int K; int Nout;
+};
+
+void launch_prep(const PrepParams& p, hipStream_t s);
+void launch_enc2(const EdgeEncParams& enc, const float* attr, int64_t n_edges, double e_total, double* stat_enc2,
+                 hipStream_t s);
+void launch_pass_a(const RoundParams& p, hipStream_t s);
+void launch_pass_b(const RoundParams& p, hipStream_t s);
+void launch_pass_c(const RoundParams& p, hipStream_t s);
+void launch_classify_e0(const EdgeEncParams& enc, const float* attr, int64_t n_edges, double e_total,
+                        const float* cls_w, const float* cls_b, int n_classes, float* logits, hipStream_t s);
+
+void launch_node_proj(const NodeProjParams& p, hipStream_t s);
+void launch_node_stat(const NodeStatParams& p, hipStream_t s);
+// h_dst[i][k] = relu(s_k * Y[i][k] + t_k) for local rows; stats over `count` rows
+void launch_bn_relu_rows(const float* Y, int64_t ldy, int64_t rows, int dim, const double* stats, const float* gamma,
+                         const float* beta, double count, float* dst, hipStream_t s);
+// dst = src (sum/max) or src / max(deg,1) (mean)
+void launch_h_final(const float* src, const int* deg, int mean, int64_t n_nodes, float* dst, hipStream_t s);
+
+int launch_gemm_bn(const GemmParams& p, hipStream_t s);   // returns 0 or MTMC_E_ARG
+
+void launch_scatter(const float* src, const int64_t* index, int64_t n_src, int64_t n_cols, int64_t dim_size,
+                    float* out, float* count, int64_t* arg_out, int mode, hipStream_t s);
+
+}  // namespace mtmc

@@ -1,0 +1,147 @@
+// Per-node kernels of the message-passing rounds (tiny next to the edge passes: O(N*32*40) flops).
+//
+//   node_proj_kernel  Pr|Pc = [h0|h] . We[:, node cols]^T  (4+4 per node),  Q = [h0|h] . Wn[:, node cols]^T (32)
+//                     -- the algebraic form of the reference's x[row], x[col] gathers + cat + Linear
+//                        (reference models/mpn.py:48,68 and :97-98): gather 16 B per edge end instead of 128 B
+//   node_stat_kernel  sum / sum of squares over all E edges of z2 = Q[row] + A.e' + b, from per-node segment
+//                     sums of e' and the degree (no pass over the edges)
+//   bn_relu_rows      h0 = relu(bn(Y_last))
+//   h_final           latent_node_feats output (mean aggregation divides by max(deg,1))
+#include "kernels.h"
+
+namespace mtmc {
+
+constexpr int kProjNodes = 32;   // nodes per block iteration
+constexpr int kProjOut = 40;     // 4 (Pr) + 4 (Pc) + 32 (Q)
+
+__global__ __launch_bounds__(256) void node_proj_kernel(NodeProjParams p) {
+  __shared__ float wt[64 * kProjOut];              // [k][j], k < hn
+  __shared__ float hs[kProjNodes * 65];            // [node][k], row stride hn+1
+  const int hn = p.hn, ldh = hn + 1;
+  for (int i = threadIdx.x; i < hn * kProjOut; i += blockDim.x) {
+    const int kk = i / kProjOut, j = i % kProjOut;
+    float w;
+    if (j < 4) w = p.ue_w[j * p.ue_ld + kk];
+    else if (j < 8) w = p.ue_w[(j - 4) * p.ue_ld + hn + kk];
+    else w = p.un_w[(j - 8) * p.un_ld + kk];
+    wt[i] = w;
+  }
+  const int nl = threadIdx.x >> 3, part = threadIdx.x & 7;
+  const int64_t n_groups = (p.n_nodes + kProjNodes - 1) / kProjNodes;
+  for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const int64_t node0 = g * kProjNodes;
+    __syncthreads();                               // wt ready / previous hs consumed
+    // stage [h0 | h] rows of 32 nodes (1024 or 2048 floats)
+    for (int i = threadIdx.x; i < kProjNodes * hn; i += blockDim.x) {
+      const int n = i / hn, kk = i % hn;
+      const int64_t node = node0 + n;
+      float v = 0.f;
+      if (node < p.n_nodes) {
+        if (hn == 64 && kk < 32) {
+          v = p.h0[node * kH + kk];
+        } else {
+          v = p.h_src[node * kH + (kk & 31)];
+          if (p.deg) { const int d = p.deg[node]; v = v / (float)(d > 1 ? d : 1); }
+        }
+      }
+      hs[n * ldh + kk] = v;
+    }
+    if (p.zero_buf) {                              // 32 nodes x 32 floats = 256 float4
+      const int64_t node = node0 + (threadIdx.x >> 3);
+      if (node < p.n_nodes)
+        reinterpret_cast<float4*>(p.zero_buf + node * kH)[threadIdx.x & 7] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int kk = 0; kk < hn; ++kk) {
+      const float hv = hs[nl * ldh + kk];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) acc[i] = fmaf(hv, wt[kk * kProjOut + part + 8 * i], acc[i]);
+    }
+    const int64_t node = node0 + nl;
+    if (node < p.n_nodes) {
+      p.P[node * 8 + part] = acc[0];
+#pragma unroll
+      for (int i = 1; i < 5; ++i) p.Q[node * kH + part + 8 * (i - 1)] = acc[i];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void node_stat_kernel(NodeStatParams p) {
+  __shared__ double red[2 * 8 * 32];
+  const int k = threadIdx.x & 31, slot = threadIdx.x >> 5;
+  float a[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a[j] = p.un_w[k * p.un_ld + p.un_eoff + j];
+  const float b = p.un_b[k];
+  double s1 = 0, s2 = 0;
+  const int64_t n_groups = (p.n_nodes + 7) / 8;
+  for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const int64_t node = g * 8 + slot;
+    if (node < p.n_nodes) {
+      const double d = (double)p.deg[node];
+      const double qb = (double)(p.Q[node * kH + k] + b);
+      double proj = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) proj += (double)a[j] * p.seg[node * 4 + j];
+      s1 += d * qb + proj;
+      s2 += d * qb * qb + 2.0 * qb * proj;
+    }
+    __syncthreads();                               // every channel has read seg[node]
+    if (node < p.n_nodes && k < 4) p.seg[node * 4 + k] = 0.0;   // ready for the next round
+  }
+  red[slot * 32 + k] = s1;
+  red[256 + slot * 32 + k] = s2;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int kk = threadIdx.x & 31, which = threadIdx.x >> 5;
+    double s = 0;
+    for (int sl = 0; sl < 8; ++sl) s += red[which * 256 + sl * 32 + kk];
+    unsafeAtomicAdd(p.stats + kRoundZ2 + which * 32 + kk, s);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_rows_kernel(const float* Y, int64_t ldy, int64_t rows, int dim,
+                                                           const double* stats, const float* gamma, const float* beta,
+                                                           double count, float* dst) {
+  const int64_t total = rows * dim;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += nthreads) {
+    const int64_t r = i / dim;
+    const int c = (int)(i % dim);
+    float s, t;
+    bn_affine(stats[c], stats[dim + c], count, gamma[c], beta[c], s, t);
+    dst[i] = fmaxf(fmaf(Y[r * ldy + c], s, t), 0.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void h_final_kernel(const float* src, const int* deg, int mean, int64_t n_nodes,
+                                                      float* dst) {
+  const int64_t total = n_nodes * kH;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += nthreads) {
+    float v = src[i];
+    if (mean) { const int d = deg[i / kH]; v = v / (float)(d > 1 ? d : 1); }
+    dst[i] = v;
+  }
+}
+
+static inline int cap_grid(int64_t blocks) { return (int)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks)); }
+
+void launch_node_proj(const NodeProjParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(node_proj_kernel, dim3(cap_grid((p.n_nodes + kProjNodes - 1) / kProjNodes)), dim3(256), 0, s, p);
+}
+void launch_node_stat(const NodeStatParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(node_stat_kernel, dim3(cap_grid((p.n_nodes + 7) / 8)), dim3(256), 0, s, p);
+}
+void launch_bn_relu_rows(const float* Y, int64_t ldy, int64_t rows, int dim, const double* stats, const float* gamma,
+                         const float* beta, double count, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(bn_relu_rows_kernel, dim3(cap_grid((rows * dim + 255) / 256)), dim3(256), 0, s, Y, ldy, rows, dim,
+                     stats, gamma, beta, count, dst);
+}
+void launch_h_final(const float* src, const int* deg, int mean, int64_t n_nodes, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(h_final_kernel, dim3(cap_grid((n_nodes * kH + 255) / 256)), dim3(256), 0, s, src, deg, mean,
+                     n_nodes, dst);
+}
+
+}  // namespace mtmc

@@ -1,0 +1,138 @@
+"""Host side of one `MOTMPNet.forward`: turns the module's parameters and the caller's tensors into the
+plain-pointer structs of include/mtmc_mpn.h and enqueues the whole forward on the current HIP stream
+with ONE library call.  PyTorch is used for device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Tuple
+
+import torch
+
+from . import _lib
+from .config import MpnSpec
+
+
+def _lin(mlp, spec_layer):
+    return mlp.fc_layers[spec_layer.lin_slot], (mlp.fc_layers[spec_layer.bn_slot] if spec_layer.bn_slot is not None else None)
+
+
+def _check_param(p: torch.Tensor, dev) -> int:
+    if p.device != dev or p.dtype != torch.float32 or not p.is_contiguous():
+        raise RuntimeError("mtmc_mpn: parameters must be contiguous float32 tensors on the input's device "
+                           f"(got {p.dtype} on {p.device})")
+    return p.data_ptr()
+
+
+class ForwardEngine:
+    def __init__(self, module):
+        self.module = module
+        self.spec: MpnSpec = module.spec
+        self.lib = _lib.load()
+        self._ws = {}
+
+    # -- parameters -> mtmc_mpn_model ------------------------------------------------------------
+    def model_struct(self, dev) -> _lib.Model:
+        m, s = self.module, self.spec
+        out = _lib.Model()
+
+        def fill(dst, mlp, layer):
+            lin, bn = _lin(mlp, layer)
+            dst.weight, dst.bias = _check_param(lin.weight, dev), _check_param(lin.bias, dev)
+            dst.gamma = _check_param(bn.weight, dev) if bn is not None else None
+            dst.beta = _check_param(bn.bias, dev) if bn is not None else None
+            dst.in_dim, dst.out_dim = layer.in_dim, layer.out_dim
+
+        if len(s.enc_node) > _lib.MAX_ENC_LAYERS:
+            raise NotImplementedError("mtmc_mpn: node encoder deeper than 8 layers")
+        out.n_enc_layers = len(s.enc_node)
+        for i, layer in enumerate(s.enc_node):
+            fill(out.enc_node[i], m.encoder.node_mlp, layer)
+        for i, layer in enumerate(s.enc_edge):
+            fill(out.enc_edge[i], m.encoder.edge_mlp, layer)
+        fill(out.upd_edge, m.MPNet.edge_model.edge_mlp, s.upd_edge[0])
+        fill(out.upd_node, m.MPNet.node_model.node_mlp, s.upd_node[0])
+        fill(out.cls, m.classifier.edge_mlp, s.cls_edge[0])
+        out.agg = _lib.AGG[s.agg]
+        out.num_enc_steps, out.num_class_steps = s.num_enc_steps, s.num_class_steps
+        out.reattach_nodes, out.reattach_edges = int(s.reattach_nodes), int(s.reattach_edges)
+        return out
+
+    def workspace(self, model, n, e, dev, stream_ptr) -> torch.Tensor:
+        need = self.lib.mtmc_mpn_workspace_bytes(C.byref(model), n, e)
+        if need == 0:
+            _lib.check(_lib.E_ARG)
+        key = (dev, stream_ptr)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=dev)
+            self._ws[key] = ws
+        return ws
+
+    # -- the call -----------------------------------------------------------------------------------
+    def check_inputs(self, x, edge_index, edge_attr):
+        if not (isinstance(x, torch.Tensor) and x.is_cuda and edge_index.is_cuda and edge_attr.is_cuda):
+            raise RuntimeError("mtmc_mpn: data.x / edge_index / edge_attr must be on a ROCm GPU -- "
+                               "this module has no CPU or PyTorch fallback path")
+        if not (x.device == edge_index.device == edge_attr.device):
+            raise RuntimeError("mtmc_mpn: all inputs must be on the same device")
+        s = self.spec
+        if x.dim() != 2 or x.shape[1] != s.enc_node[0].in_dim:
+            raise RuntimeError(f"mtmc_mpn: data.x must be [N, {s.enc_node[0].in_dim}], got {tuple(x.shape)}")
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise RuntimeError(f"mtmc_mpn: data.edge_index must be [2, E], got {tuple(edge_index.shape)}")
+        e = edge_index.shape[1]
+        if edge_attr.dim() != 2 or tuple(edge_attr.shape) != (e, s.enc_edge[0].in_dim):
+            raise RuntimeError(f"mtmc_mpn: data.edge_attr must be [{e}, {s.enc_edge[0].in_dim}], got {tuple(edge_attr.shape)}")
+        if x.dtype != torch.float32 or edge_attr.dtype != torch.float32:
+            raise RuntimeError("mtmc_mpn: x and edge_attr must be float32")
+        if edge_index.dtype != torch.int64:
+            raise RuntimeError("mtmc_mpn: edge_index must be int64")
+
+    def __call__(self, x, edge_index, edge_attr, training=False) -> Tuple[List[torch.Tensor], torch.Tensor]:
+        self.check_inputs(x, edge_index, edge_attr)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.module.parameters())):
+            raise NotImplementedError(
+                "mtmc_mpn: the HIP backward pass is not built yet; call under torch.no_grad() "
+                "(inference, as main.py / inference.py:374 do)")
+        if training:
+            raise NotImplementedError("mtmc_mpn: training-mode forward (Dropout masks) is not built yet; use .eval()")
+        s, dev = self.spec, x.device
+        n, e = x.shape[0], edge_index.shape[1]
+        if x.stride(1) != 1 or x.stride(0) % 4 != 0:
+            x = x.contiguous()
+        if not edge_attr.is_contiguous():
+            edge_attr = edge_attr.contiguous()
+        if e > 0 and edge_index.stride(1) < 1:
+            edge_index = edge_index.contiguous()
+        n_out = s.num_class_steps if s.num_enc_steps > 0 else 1
+        n_out = min(n_out, max(s.num_enc_steps, 1))
+        n_cls = s.cls_edge[0].out_dim
+        logits = torch.empty((n_out, e, n_cls), dtype=torch.float32, device=dev)
+        h = torch.empty((n, s.node_dim), dtype=torch.float32, device=dev)
+
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            model = self.model_struct(dev)
+            ws = self.workspace(model, n, e, dev, stream)
+            call = _lib.Call()
+            call.x, call.x_row_stride = x.data_ptr(), x.stride(0)
+            call.row = edge_index[0].data_ptr() if e > 0 else None
+            call.col = edge_index[1].data_ptr() if e > 0 else None
+            call.idx_stride = edge_index.stride(1) if e > 0 else 1
+            call.edge_attr = edge_attr.data_ptr() if e > 0 else ws.data_ptr()
+            call.n_nodes, call.n_edges, call.n_edges_total = n, e, e
+            call.node_lo, call.node_hi = 0, n
+            call.logits = logits.data_ptr() if logits.numel() else ws.data_ptr()
+            call.h_out = h.data_ptr()
+            call.workspace, call.workspace_bytes = ws.data_ptr(), ws.numel()
+            call.training, call.flags, call.seed = 0, 0, 0
+            call.stream = stream
+            _lib.check(self.lib.mtmc_mpn_forward(C.byref(model), C.byref(call)))
+            if self.module.check_indices:
+                lay = _lib.WsLayout()
+                _lib.check(self.lib.mtmc_mpn_workspace_layout(C.byref(model), n, e, C.byref(lay)))
+                flags = ws[lay.flags_off:lay.flags_off + 32].view(torch.int32).cpu()
+                if int(flags[1]) != 0:
+                    raise IndexError("mtmc_mpn: edge_index holds node ids outside [0, N)")
+        return [logits[i] for i in range(n_out)], h

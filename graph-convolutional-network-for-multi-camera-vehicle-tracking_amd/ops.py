@@ -1,0 +1,106 @@
+"""Stand-alone ops of the hot path, for callers that use the pieces on their own:
+
+  scatter_add / scatter_mean / scatter_max   the call forms of the third-party `torch_scatter` op the
+      reference aggregates with (`scatter_*(src, index, dim=0, dim_size=N)`, reference models/mpn.py:196-202)
+  mlp_forward                                `MLP.forward` (reference models/mlp.py:32-33), eval mode
+
+All of them run HIP kernels through the C ABI; CPU tensors are refused.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _prep(src, index, dim, dim_size):
+    if not (src.is_cuda and index.is_cuda):
+        raise RuntimeError("mtmc_mpn.scatter_*: tensors must be on a ROCm GPU (no CPU path)")
+    if dim not in (0, -src.dim()):
+        raise NotImplementedError("mtmc_mpn.scatter_*: only dim=0 (the reference's call form) is implemented")
+    if index.dim() != 1 or index.shape[0] != src.shape[0]:
+        raise RuntimeError("mtmc_mpn.scatter_*: index must be 1-D with one entry per row of src")
+    if dim_size is None:
+        dim_size = int(index.max()) + 1 if index.numel() else 0
+    src2 = src.reshape(src.shape[0], -1).contiguous().float()
+    return src2, index.contiguous().long(), int(dim_size)
+
+
+def scatter_add(src, index, dim=0, out=None, dim_size=None):
+    if out is not None:
+        raise NotImplementedError("mtmc_mpn.scatter_add: `out=` is not supported")
+    s2, idx, n = _prep(src, index, dim, dim_size)
+    res = torch.empty((n, s2.shape[1]), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        _lib.check(_lib.load().mtmc_scatter_add(s2.data_ptr(), idx.data_ptr(), s2.shape[0], s2.shape[1], n,
+                                                res.data_ptr(), _stream(src.device)))
+    return res.reshape((n,) + tuple(src.shape[1:]))
+
+
+scatter_sum = scatter_add
+
+
+def scatter_mean(src, index, dim=0, out=None, dim_size=None):
+    if out is not None:
+        raise NotImplementedError("mtmc_mpn.scatter_mean: `out=` is not supported")
+    s2, idx, n = _prep(src, index, dim, dim_size)
+    res = torch.empty((n, s2.shape[1]), dtype=torch.float32, device=src.device)
+    cnt = torch.empty((max(n, 1),), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        _lib.check(_lib.load().mtmc_scatter_mean(s2.data_ptr(), idx.data_ptr(), s2.shape[0], s2.shape[1], n,
+                                                 res.data_ptr(), cnt.data_ptr(), _stream(src.device)))
+    return res.reshape((n,) + tuple(src.shape[1:]))
+
+
+def scatter_max(src, index, dim=0, out=None, dim_size=None):
+    """Returns (values, argmax) like torch_scatter; rows nobody writes hold 0 and argmax = src.size(0)."""
+    if out is not None:
+        raise NotImplementedError("mtmc_mpn.scatter_max: `out=` is not supported")
+    s2, idx, n = _prep(src, index, dim, dim_size)
+    res = torch.empty((n, s2.shape[1]), dtype=torch.float32, device=src.device)
+    arg = torch.empty((n, s2.shape[1]), dtype=torch.int64, device=src.device)
+    with torch.cuda.device(src.device):
+        _lib.check(_lib.load().mtmc_scatter_max(s2.data_ptr(), idx.data_ptr(), s2.shape[0], s2.shape[1], n,
+                                                res.data_ptr(), arg.data_ptr(), _stream(src.device)))
+    shape = (n,) + tuple(src.shape[1:])
+    return res.reshape(shape), arg.reshape(shape)
+
+
+def mlp_forward(mlp, inp: torch.Tensor) -> torch.Tensor:
+    """Eval-mode `MLP.forward`: per hidden layer Linear -> BatchNorm1d (batch statistics) -> ReLU."""
+    if not inp.is_cuda:
+        raise RuntimeError("mtmc_mpn.MLP: input must be on a ROCm GPU (no CPU path)")
+    if mlp.training and any(l.dropout_p for l in mlp.layers):
+        raise NotImplementedError("mtmc_mpn.MLP: training-mode Dropout is not built yet; use .eval()")
+    if torch.is_grad_enabled() and (inp.requires_grad or any(p.requires_grad for p in mlp.parameters())):
+        raise NotImplementedError("mtmc_mpn.MLP: backward is not built yet; call under torch.no_grad()")
+    lib = _lib.load()
+    a = inp.float()
+    if a.stride(-1) != 1:
+        a = a.contiguous()
+    with torch.cuda.device(inp.device):
+        for spec in mlp.layers:
+            lin = mlp.fc_layers[spec.lin_slot]
+            bn = mlp.fc_layers[spec.bn_slot] if spec.bn_slot is not None else None
+            lay = _lib.Layer()
+            lay.weight, lay.bias = lin.weight.data_ptr(), lin.bias.data_ptr()
+            lay.gamma = bn.weight.data_ptr() if bn is not None else None
+            lay.beta = bn.bias.data_ptr() if bn is not None else None
+            lay.in_dim, lay.out_dim = spec.in_dim, spec.out_dim
+            if bn is not None and a.shape[0] < 2:
+                raise ValueError("Expected more than 1 value per channel when training, got input size {}".format(
+                    list(a.shape)))
+            y = torch.empty((a.shape[0], spec.out_dim), dtype=torch.float32, device=inp.device)
+            stats = torch.empty((2 * spec.out_dim,), dtype=torch.float64, device=inp.device)
+            _lib.check(lib.mtmc_mlp_layer_forward(C.byref(lay), a.data_ptr(), a.stride(0), a.shape[0], y.data_ptr(),
+                                                  stats.data_ptr(), _stream(inp.device)))
+            if spec.relu and bn is None:
+                y = torch.relu_(y)
+            a = y
+    return a

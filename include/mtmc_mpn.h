@@ -1,0 +1,160 @@
+/*
+ * mtmc_mpn.h -- C ABI of the MI355X (gfx950) message-passing-network forward.
+ *
+ * This is the drop-in boundary for ONE hot path of
+ * elun15/Graph-Convolutional-Network-for-Multi-Camera-Vehicle-Tracking: `MOTMPNet.forward`
+ * (reference models/mpn.py:250-299).  Every pointer is a plain device pointer into HBM, every
+ * size a plain integer; there are no torch (or any other framework) types in the signatures.
+ * The host side that mirrors the reference's nn.Module interface (mtmc_mpn/modules.py) binds
+ * these entry points with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Reference interface each entry point replaces:
+ *   mtmc_mpn_forward           <- MOTMPNet.forward              models/mpn.py:250-299
+ *     (node/edge encoders       MLPGraphIndependent.forward      models/mpn.py:128-142,
+ *      MLP = Linear+BN+ReLU     MLP.forward                      models/mlp.py:11-33,
+ *      one round                MetaLayer.forward                models/mpn.py:32-54,
+ *      edge update              EdgeModel.forward                models/mpn.py:67-69,
+ *      node update + aggregate  NodeModel.forward                models/mpn.py:97-99,
+ *      classifier               MLPGraphIndependent.forward      models/mpn.py:291-292)
+ *   mtmc_mpn_run_phase         <- the same, cut at the points where a multi-GPU run exchanges
+ *                                 BatchNorm statistics / node states (no reference counterpart:
+ *                                 the reference is single-GPU)
+ *   mtmc_scatter_{add,mean,max}<- torch_scatter.scatter_{add,mean,max}(src, index, dim=0, dim_size)
+ *                                 (third-party pytorch-scatter 2.0.8; call sites models/mpn.py:196,199,202)
+ *   mtmc_mlp_forward           <- MLP.forward as a stand-alone op  models/mlp.py:32-33
+ *
+ * All floating tensors are fp32, row-major, contiguous unless a stride argument says otherwise;
+ * BatchNorm statistics are accumulated in fp64.  All work is enqueued on `stream` (a hipStream_t
+ * passed as void*; NULL = the default stream); no entry point synchronises or allocates.
+ * Return value: 0 on success, a negative MTMC_E_* code otherwise (mtmc_mpn_last_error() gives text).
+ */
+#ifndef MTMC_MPN_H
+#define MTMC_MPN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTMC_MPN_ABI_VERSION 1
+
+#define MTMC_MAX_ENC_LAYERS 8   /* hidden layers of the node encoder MLP          */
+#define MTMC_NODE_DIM 32        /* H : width of the node state the kernels are built for */
+#define MTMC_EDGE_DIM 4         /* He: width of the edge state                    */
+#define MTMC_MAX_CLASSES 4      /* classifier outputs per edge (reference: 2)     */
+
+enum { MTMC_AGG_SUM = 0, MTMC_AGG_MEAN = 1, MTMC_AGG_MAX = 2 };
+
+enum {
+  MTMC_OK = 0,
+  MTMC_E_ARG = -1,        /* bad dimension / NULL pointer / unsupported shape      */
+  MTMC_E_WORKSPACE = -2,  /* workspace too small or misaligned                     */
+  MTMC_E_HIP = -3,        /* a HIP runtime call failed                             */
+  MTMC_E_ROWS = -4        /* fewer than 2 rows under a BatchNorm (the reference raises ValueError) */
+};
+
+/* One Linear(+BatchNorm affine) group: weight [out,in] row-major, bias [out], gamma/beta [out]. */
+typedef struct mtmc_layer {
+  const float* weight;
+  const float* bias;
+  const float* gamma;   /* BatchNorm1d.weight */
+  const float* beta;    /* BatchNorm1d.bias   */
+  int32_t in_dim;
+  int32_t out_dim;
+} mtmc_layer;
+
+/* The 34 parameter tensors of the reference model + its structural flags. */
+typedef struct mtmc_mpn_model {
+  int32_t n_enc_layers;                         /* node encoder: 2048->1024->512->128->32 => 4 */
+  mtmc_layer enc_node[MTMC_MAX_ENC_LAYERS];     /* encoder.node_mlp.fc_layers.{0,4,8,12}(+1)   */
+  mtmc_layer enc_edge[2];                       /* encoder.edge_mlp: in(1|2)->4->4              */
+  mtmc_layer upd_edge;                          /* MPNet.edge_model.edge_mlp: [4, nf*64+ef*4]   */
+  mtmc_layer upd_node;                          /* MPNet.node_model.node_mlp: [32, nf*32+4]     */
+  mtmc_layer cls;                               /* classifier.edge_mlp.fc_layers.0: [C,4], no BN */
+  int32_t agg;                                  /* MTMC_AGG_*  (node_agg_fn)                    */
+  int32_t num_enc_steps;                        /* L                                            */
+  int32_t num_class_steps;                      /* Cs                                           */
+  int32_t reattach_nodes;                       /* reattach_initial_nodes                       */
+  int32_t reattach_edges;                       /* reattach_initial_edges                       */
+} mtmc_mpn_model;
+
+/* One forward call.  For a single GPU: node_lo=0, node_hi=n_nodes, n_edges_total=n_edges. */
+typedef struct mtmc_mpn_call {
+  const float* x;            /* [node_hi-node_lo, F] rows node_lo.. of data.x           */
+  int64_t x_row_stride;      /* elements between consecutive rows of x                  */
+  const int64_t* row;        /* data.edge_index[0]: element e at row[e*idx_stride]      */
+  const int64_t* col;        /* data.edge_index[1]                                      */
+  int64_t idx_stride;        /* 1 for a contiguous [2,E]; 2 for the callers' [E,2].T view */
+  const float* edge_attr;    /* [n_edges, edge_in_dim] contiguous                       */
+  int64_t n_nodes;           /* N (global)                                              */
+  int64_t n_edges;           /* E held by this call (the local shard)                   */
+  int64_t n_edges_total;     /* E over all shards: the BatchNorm row count              */
+  int64_t node_lo, node_hi;  /* node rows this call encodes                             */
+  float* logits;             /* out [n_outputs][n_edges][C]; n_outputs = Cs, or 1 if L==0 */
+  float* h_out;              /* out [n_nodes][32] = latent_node_feats                   */
+  void* workspace;           /* >= mtmc_mpn_workspace_bytes(), 256-byte aligned         */
+  size_t workspace_bytes;
+  int32_t training;          /* 0: eval (Dropout = identity).  1: not implemented yet   */
+  int32_t flags;             /* MTMC_F_*                                                */
+  uint64_t seed;
+  void* stream;              /* hipStream_t                                             */
+} mtmc_mpn_call;
+
+#define MTMC_F_DETERMINISTIC 1   /* reserved: order-independent segment sums            */
+
+/* Byte offsets inside the workspace of the regions a multi-GPU host exchanges between phases. */
+typedef struct mtmc_ws_layout {
+  size_t total_bytes;
+  size_t zero_bytes;         /* the leading region [0, zero_bytes) is cleared by MTMC_PH_BEGIN   */
+  size_t flags_off;          /* int32[8]: [0] rows out of order, [1] indices out of range        */
+  size_t stat_attr_off;      /* f64[2+4]      edge_attr first/second moments                     */
+  size_t stat_enc2_off;      /* f64[4+16]     moments of the edge-encoder hidden layer           */
+  size_t stat_enc_node_off;  /* f64[2*sum(out dims)] node-encoder column sums / sums of squares  */
+  size_t stat_round_off;     /* f64[L][8+20+64] per round: z1 stats, e' moments, z2 stats        */
+  size_t deg_off;            /* i32[N]        out-degree (row histogram)                         */
+  size_t seg_off;            /* f64[N][4]     per-node segment sums of e'                        */
+  size_t h0_off;             /* f32[N][32]    encoded node state                                 */
+  size_t h_acc_off[2];       /* f32[N][32] x2 aggregation ping-pong                              */
+} mtmc_ws_layout;
+
+enum {                       /* phases in forward order; `arg` = encoder layer or round (0-based) */
+  MTMC_PH_BEGIN = 0,         /* clear statistics; int64 -> int32 indices; degree; attr moments   */
+  MTMC_PH_EDGE_ENC = 1,      /* moments of the edge-encoder hidden layer                         */
+  MTMC_PH_NODE_ENC = 2,      /* arg = layer: GEMM + column statistics                            */
+  MTMC_PH_NODE_H0 = 3,       /* h0 = relu(bn(Y_last)) for rows [node_lo,node_hi)                 */
+  MTMC_PH_ROUND_PROJ = 4,    /* arg = round: per-node projections Pr|Pc|Q, clear next h buffer   */
+  MTMC_PH_ROUND_A = 5,       /* statistics of the edge-update pre-activation                     */
+  MTMC_PH_ROUND_B = 6,       /* e' (stored), its moments and per-node segment sums               */
+  MTMC_PH_ROUND_STAT = 7,    /* statistics of the node-update pre-activation by moments          */
+  MTMC_PH_ROUND_C = 8,       /* messages, aggregation into h, classifier logits                  */
+  MTMC_PH_END = 9            /* mean scaling / copy of the final node state to h_out             */
+};
+
+int32_t mtmc_mpn_abi_version(void);
+const char* mtmc_mpn_last_error(void);
+size_t mtmc_mpn_workspace_bytes(const mtmc_mpn_model* model, int64_t n_nodes, int64_t n_edges);
+int32_t mtmc_mpn_workspace_layout(const mtmc_mpn_model* model, int64_t n_nodes, int64_t n_edges,
+                                  mtmc_ws_layout* out);
+int32_t mtmc_mpn_forward(const mtmc_mpn_model* model, const mtmc_mpn_call* call);
+int32_t mtmc_mpn_run_phase(const mtmc_mpn_model* model, const mtmc_mpn_call* call, int32_t phase, int32_t arg);
+
+/* out[dim_size, C] (fp32) <- scatter of src[E, C] by index[E] along dim 0; rows nobody writes are 0.
+ * mean divides by max(count,1); max also writes arg_out[dim_size, C] (int64, E where untouched) if non-NULL. */
+int32_t mtmc_scatter_add(const float* src, const int64_t* index, int64_t n_src, int64_t n_cols,
+                         int64_t dim_size, float* out, void* stream);
+int32_t mtmc_scatter_mean(const float* src, const int64_t* index, int64_t n_src, int64_t n_cols,
+                          int64_t dim_size, float* out, float* count_scratch, void* stream);
+int32_t mtmc_scatter_max(const float* src, const int64_t* index, int64_t n_src, int64_t n_cols,
+                         int64_t dim_size, float* out, int64_t* arg_out, void* stream);
+
+/* y[rows, out] = relu(batchnorm_batchstats(x[rows,in] . W^T + b)) for one Linear+BN+ReLU group
+ * (gamma == NULL: bare Linear).  stats_scratch: f64[2*out], y_raw aliases y. */
+int32_t mtmc_mlp_layer_forward(const mtmc_layer* layer, const float* x, int64_t x_row_stride, int64_t rows,
+                               float* y, double* stats_scratch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTMC_MPN_H */
