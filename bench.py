@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""bench.py -- MPN-forward edges/s on MI355X, with the roofline of the dominant kernel and the CPU baseline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload auto|s02|s02_L1|s02_tracker|cfg4|cfg5]
+
+A step = one full `MOTMPNet.forward` (all L rounds, eval mode, inputs resident in HBM).  Metric and
+workloads are BASELINE.json's: at 1 GPU the AIC19-S02 graph (ground-truth topology 124/90/99/137
+tracklets -> N=450, E=150 454; the real tracker files are not available offline) at L=3, Cs=1; the same
+run also reports the 100k-node / 10M-edge stress graph (config 4) under "stress".  With --gpus N > 1 the
+1M-node / 100M-edge graph (config 5) is edge-range partitioned over the ranks (strong scaling).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import mtmc_mpn  # noqa: E402
+from mtmc_mpn import _lib, graphs  # noqa: E402
+
+ARCH = "resnet101"
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # fp32-input MFMA dense peak
+
+PHASE_NAMES = {_lib.PH_BEGIN: "memset+prep_kernel", _lib.PH_EDGE_ENC: "enc2_kernel", _lib.PH_NODE_ENC: "gemm_bn_kernel",
+               _lib.PH_NODE_H0: "bn_relu_rows_kernel", _lib.PH_ROUND_PROJ: "node_proj_kernel",
+               _lib.PH_ROUND_A: "pass_a_kernel", _lib.PH_ROUND_B: "pass_b_kernel", _lib.PH_ROUND_STAT: "node_stat_kernel",
+               _lib.PH_ROUND_C: "pass_c_kernel", _lib.PH_END: "h_final_kernel"}
+
+WORKLOADS = {
+    # name: (description, L, Cs)
+    "s02": ("AIC19-S02 ground-truth topology, cams 124/90/99/137: N=450 E=150454", 3, 1),
+    "s02_L1": ("AIC19-S02 ground-truth topology (shipped config L=1)", 1, 1),
+    "s02_tracker": ("AIC19-S02 tracker-scale topology, cams 250/221/281/250: N=1002 E=751202", 3, 1),
+    "cfg4": ("synthetic 100k nodes / 10M edges, sorted rows", 3, 1),
+    "cfg5": ("synthetic 1M nodes / 100M edges, sorted rows", 3, 1),
+}
+
+
+def make_workload(name, device):
+    if name in ("s02", "s02_L1"):
+        d = graphs.camera_graph(graphs.S02_GT_CAMS, seed=2)
+    elif name == "s02_tracker":
+        d = graphs.camera_graph(graphs.S02_TRACKER_CAMS, seed=2)
+    elif name == "cfg4":
+        d = graphs.stress_graph(100_000, 5_000_000, seed=4, device=device)
+    elif name == "cfg5":
+        d = graphs.stress_graph(1_000_000, 50_000_000, seed=5, device=device)
+    else:
+        raise ValueError(name)
+    ei = d.edge_index
+    if ei.device.type == "cpu":
+        ei = ei.t().contiguous().to(device).t() if not ei.is_contiguous() else ei.to(device)   # callers' [E,2].T view
+    return types.SimpleNamespace(x=d.x.to(device), edge_index=ei, edge_attr=d.edge_attr.to(device))
+
+
+def algorithmic_bytes_forward(n, e, L, cs, f=2048):
+    """SURVEY.md 8(d), reference formulation (fp32 + int64): B_fwd = B_enc + L*B_round + Cs*B_cls."""
+    return (f * 4 + 128) * n + 24 * e + L * (176 * e + 256 * n) + cs * 8 * e
+
+
+def phase_cost(ph, arg, spec, n, e):
+    """Algorithmic work of one launch of the phase's kernel: ('hbm', bytes) or ('mfma', flops).
+    Per-kernel compulsory traffic of this build's formulation: streamed reads +
+    writes, per-node tables counted once."""
+    if ph == _lib.PH_NODE_ENC:
+        lay = spec.enc_node[arg]
+        return "mfma", 2.0 * n * lay.in_dim * lay.out_dim
+    first = arg == 0
+    e_in = 8 if (first and not spec.reattach_edges) else (24 if spec.reattach_edges and not first else 16 if not first else 8)
+    table = {
+        _lib.PH_BEGIN: 16 * e + 8 * e + 8 * e + 4 * n,                 # int64 row/col + attr in, int32 row/col out, degree
+        _lib.PH_EDGE_ENC: 8 * e,
+        _lib.PH_NODE_H0: 256 * n,
+        _lib.PH_ROUND_PROJ: (128 + 32 + 128 + 128) * n,                # h in, P, Q out, cleared aggregation buffer
+        _lib.PH_ROUND_A: (8 + e_in) * e + 32 * n,
+        _lib.PH_ROUND_B: (8 + e_in + 16) * e + (32 + 32) * n,
+        _lib.PH_ROUND_STAT: (128 + 4 + 32) * n,
+        _lib.PH_ROUND_C: (4 + 16) * e + (128 + 128) * n + (8 * e if arg >= spec.num_enc_steps - spec.num_class_steps else 0),
+        _lib.PH_END: 256 * n,
+    }
+    return "hbm", float(table[ph])
+
+
+def time_forward(model, data, steps, warmup, dist=None):
+    dev = data.x.device
+    with torch.no_grad():
+        for _ in range(warmup):
+            model(data)
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model(data)
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        t1 = time.perf_counter()
+    return (t1 - t0) / steps
+
+
+def time_phases(model, data, iters):
+    """Per-kernel durations from HIP events recorded on the launch stream around every phase."""
+    from mtmc_mpn import engine
+    eng = model._engine or engine.ForwardEngine(model)
+    seq = eng.phase_list()
+    sums = [0.0] * len(seq)
+    with torch.no_grad():
+        prep = eng.prepare(data.x, data.edge_index, data.edge_attr)
+        for it in range(iters + 2):
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in seq]
+            idx = [0]
+
+            def before(ph, arg):
+                evs[idx[0]][0].record()
+
+            def after(ph, arg):
+                evs[idx[0]][1].record()
+                idx[0] += 1
+            eng.run_phases(prep, after_phase=after, before_phase=before)
+            torch.cuda.synchronize()
+            if it >= 2:
+                for i, (a, b) in enumerate(evs):
+                    sums[i] += a.elapsed_time(b)
+    return seq, [s / iters for s in sums]
+
+
+def cpu_baseline(name, params, sd, data, max_seconds=25.0):
+    """The CPU oracle (bit-equal to the reference's CPU PyTorch path in the build container) timed on
+    this host's cores, on a bounded sample of the workload."""
+    from oracle import mpn_oracle
+    # the GPU box hands one GPU's share of the host (16 cores) to this process; more threads than that
+    # only oversubscribe ATen's small ops (measured: 256 threads are >100x slower than 16)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(avail, 16)))
+    e_full = data.edge_index.shape[1]
+    if e_full <= 1_000_000:
+        x, ei, ea = data.x.cpu(), data.edge_index.cpu(), data.edge_attr.cpu()
+        sample = "full workload"
+    else:
+        scale = 10 if e_full <= 20_000_000 else 100
+        d = graphs.stress_graph(data.x.shape[0] // scale, e_full // (2 * scale), seed=4)
+        x, ei, ea = d.x, d.edge_index, d.edge_attr
+        sample = f"same recipe at 1/{scale} scale: {x.shape[0]} nodes / {ei.shape[1]} edges (edges/s is size-normalised)"
+    sd_cpu = {k: v.cpu() for k, v in sd.items()}
+    times = []
+    with torch.no_grad():
+        t_start = time.perf_counter()
+        for i in range(13):
+            t0 = time.perf_counter()
+            mpn_oracle.forward(sd_cpu, copy.deepcopy(params), ARCH, x, ei, ea)
+            dt = time.perf_counter() - t0
+            if i >= 3:
+                times.append(dt)
+            if time.perf_counter() - t_start > max_seconds and len(times) >= 2:
+                break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": ei.shape[1] / med, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{sample}; median of {len(times)} forwards after 3 warm-ups, {med * 1e3:.1f} ms each",
+            "host_cpu_count": os.cpu_count()}
+
+
+def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
+    desc, L, cs = WORKLOADS[name]
+    params = mtmc_mpn.default_params(num_enc_steps=L, num_class_steps=cs)
+    torch.manual_seed(0)
+    model = mtmc_mpn.MOTMPNet(copy.deepcopy(params), None, ARCH).to(device).eval()
+    data = make_workload(name, device)
+    n, e = data.x.shape[0], data.edge_index.shape[1]
+    sec = time_forward(model, data, steps, warmup)
+    seq, ms = time_phases(model, data, phase_iters)
+    spec = model.spec
+    # dominant kernel = the phase kind with the largest summed time
+    by_kind = {}
+    for (ph, arg), t in zip(seq, ms):
+        key = (ph, arg) if ph == _lib.PH_NODE_ENC else (ph, -1)
+        by_kind.setdefault(key, []).append(((ph, arg), t))
+    dom_key = max(by_kind, key=lambda k: sum(t for _, t in by_kind[k]))
+    launches = by_kind[dom_key]
+    avg_ms = sum(t for _, t in launches) / len(launches)
+    kinds = [phase_cost(ph, arg, spec, n, e) for (ph, arg), _ in launches]
+    bound = kinds[0][0]
+    work = sum(w for _, w in kinds) / len(kinds)
+    if bound == "mfma":
+        achieved, peak, unit = work / (avg_ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+    else:
+        achieved, peak, unit = work / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+    kname = PHASE_NAMES[dom_key[0]] + (f"[layer {dom_key[1]}]" if dom_key[0] == _lib.PH_NODE_ENC else "")
+    roofline = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
+                "traffic": None, "kernel": kname, "avg_kernel_ms": avg_ms, "launches_per_step": len(launches),
+                "algorithmic_per_launch": work}
+    b_fwd = algorithmic_bytes_forward(n, e, L, cs)
+    phases = {}
+    for (ph, arg), t in zip(seq, ms):
+        k = PHASE_NAMES[ph] + (f"[{arg}]" if ph == _lib.PH_NODE_ENC else "")
+        phases[k] = phases.get(k, 0.0) + t
+    res = {"workload": name, "description": desc, "N": n, "E": e, "L": L, "Cs": cs,
+           "value": e / sec, "ms_per_step": sec * 1e3, "edge_rounds_per_s": e * L / sec,
+           "roofline": roofline,
+           "forward_algorithmic": {"bytes": b_fwd, "GBps": b_fwd / sec / 1e9, "frac_of_hbm_peak": b_fwd / sec / 1e9 / HBM_PEAK_GBS,
+                                   "note": "SURVEY 8(d) reference-formulation bytes / whole-forward time"},
+           "phase_ms_sum": sum(ms), "phase_ms": {k: round(v, 4) for k, v in phases.items()}}
+    if with_cpu:
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        res["cpu_baseline"] = cpu_baseline(name, params, sd, data)
+    del data, model
+    torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="auto")
+    ap.add_argument("--no-stress", action="store_true", help="skip the config-4 stress graph in the 1-GPU run")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        from bench_dist import main_distributed   # multi-GPU leg lives beside this file
+        return main_distributed(args)
+
+    device = torch.device("cuda:0")
+    torch.cuda.set_device(device)
+    name = "s02" if args.workload == "auto" else args.workload
+    res = run_single(name, device, args.steps, args.warmup, with_cpu=not args.no_cpu)
+    line = {"metric": "MPN forward edges/sec (+ achieved roofline fraction of the dominant kernel)",
+            "value": res["value"], "unit": "edges/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (seeded features on the reference's S02 ground-truth topology; random-init weights)",
+            "config": {"workload": f"{name}: {res['description']}, L={res['L']}, Cs={res['Cs']}, eval forward",
+                       "N": res["N"], "E": res["E"], "parallelism": "1 GPU"},
+            "roofline": res["roofline"], "cpu_baseline": res.get("cpu_baseline"),
+            "forward_algorithmic": res["forward_algorithmic"], "edge_rounds_per_s": res["edge_rounds_per_s"],
+            "phase_ms": res["phase_ms"]}
+    if args.workload == "auto" and not args.no_stress:
+        st = run_single("cfg4", device, max(5, args.steps // 10), max(2, args.warmup // 10), with_cpu=not args.no_cpu,
+                        phase_iters=5)
+        line["stress"] = st
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -61,8 +61,8 @@ void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* lo) {
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
   const int L = m->num_enc_steps;
   lo->pub.flags_off = take(8 * sizeof(int32_t));
-  lo->pub.stat_attr_off = take(mtmc::kStatAttr * sizeof(double));
-  lo->pub.stat_enc2_off = take(mtmc::kStatEnc2 * sizeof(double));
+  lo->pub.stat_attr_off = take((size_t)mtmc::kStatRep * mtmc::kAttrStride * sizeof(double));
+  lo->pub.stat_enc2_off = take((size_t)mtmc::kStatRep * mtmc::kEnc2Stride * sizeof(double));
   size_t enc_stats = 0;
   for (int l = 0; l < m->n_enc_layers; ++l) enc_stats += 2 * (size_t)m->enc_node[l].out_dim;
   lo->pub.stat_enc_node_off = take(enc_stats * sizeof(double));
@@ -71,7 +71,7 @@ void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* lo) {
     lo->stat_enc_layer[l] = lo->pub.stat_enc_node_off + acc * sizeof(double);
     acc += 2 * (size_t)m->enc_node[l].out_dim;
   }
-  lo->pub.stat_round_off = take((size_t)(L > 0 ? L : 1) * mtmc::kRoundStride * sizeof(double));
+  lo->pub.stat_round_off = take((size_t)(L > 0 ? L : 1) * mtmc::kStatRep * mtmc::kRoundStride * sizeof(double));
   lo->pub.deg_off = take((size_t)N * sizeof(int32_t));
   lo->pub.seg_off = take((size_t)N * 4 * sizeof(double));
   lo->pub.zero_bytes = off;
@@ -146,7 +146,7 @@ mtmc::RoundParams round_params(const Ctx& x, int r) {
   p.un_w = m->upd_node.weight; p.un_b = m->upd_node.bias; p.un_g = m->upd_node.gamma; p.un_bt = m->upd_node.beta;
   p.un_ld = m->upd_node.in_dim; p.un_eoff = hn;
   p.cls_w = m->cls.weight; p.cls_b = m->cls.bias; p.n_classes = m->cls.out_dim;
-  p.stats = x.at<double>(x.lo.pub.stat_round_off) + (size_t)r * mtmc::kRoundStride;
+  p.stats = x.at<double>(x.lo.pub.stat_round_off) + (size_t)r * mtmc::kStatRep * mtmc::kRoundStride;
   p.seg = x.at<double>(x.lo.pub.seg_off);
   p.h_acc = x.at<float>(x.lo.pub.h_acc_off[r & 1]);
   const int step = r + 1;
@@ -241,7 +241,7 @@ int run_phase(const Ctx& x, int phase, int arg) {
       p.Q = x.at<float>(x.lo.Q); p.deg = x.at<int>(x.lo.pub.deg_off); p.seg = x.at<double>(x.lo.pub.seg_off);
       p.un_w = m->upd_node.weight; p.un_b = m->upd_node.bias; p.un_ld = m->upd_node.in_dim;
       p.un_eoff = (m->reattach_nodes ? 2 : 1) * MTMC_NODE_DIM;
-      p.stats = x.at<double>(x.lo.pub.stat_round_off) + (size_t)arg * mtmc::kRoundStride;
+      p.stats = x.at<double>(x.lo.pub.stat_round_off) + (size_t)arg * mtmc::kStatRep * mtmc::kRoundStride;
       p.n_nodes = c->n_nodes;
       mtmc::launch_node_stat(p, s);
       break;

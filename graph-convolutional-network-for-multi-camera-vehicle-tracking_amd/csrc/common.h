@@ -20,7 +20,15 @@ constexpr int kHe = 4;    // edge state width
 // round stats  : z1 sum[4] | z1 sumsq[4] | e' m1[4] | e' m2 packed[10] | z2 sum[32] | z2 sumsq[32]
 constexpr int kStatAttr = 6;
 constexpr int kStatEnc2 = 16;
-constexpr int kRoundZ1 = 0, kRoundM1 = 8, kRoundM2 = 12, kRoundZ2 = 22, kRoundStride = 88;
+constexpr int kRoundZ1 = 0, kRoundM1 = 8, kRoundM2 = 12, kRoundZ2 = 22, kRoundStats = 86;
+// Every such block is kept in kStatRep replicas (each padded to a 128-byte multiple): a workgroup adds its
+// partial sums to replica blockIdx % kStatRep, the consumer adds the replicas up.  Hundreds of workgroups
+// adding to ONE cache line serialise at the memory side (float atomics run an order of magnitude slower
+// on a single row, MI355X_MICROARCH 'Global float atomics'); 16 lines remove that.
+constexpr int kStatRep = 16;
+__host__ __device__ __forceinline__ constexpr int stat_stride(int n) { return (n + 15) / 16 * 16; }
+constexpr int kAttrStride = stat_stride(kStatAttr), kEnc2Stride = stat_stride(kStatEnc2),
+              kRoundStride = stat_stride(kRoundStats);   // doubles per replica
 
 __host__ __device__ __forceinline__ constexpr int tri(int n, int i, int j) { return i * n - i * (i - 1) / 2 + (j - i); }
 
@@ -30,10 +38,21 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;   // lane 0 holds the total
 }
 
-// Block-wide sum of NV per-thread doubles; result atomically added to dst[0..NV).
+// dst[i] = sum over replicas of src[r*stride + i], i < n  (cooperative; caller synchronises afterwards)
+__device__ __forceinline__ void stat_gather(const double* src, int n, int stride, double* dst) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    double s = 0;
+#pragma unroll
+    for (int r = 0; r < kStatRep; ++r) s += src[r * stride + i];
+    dst[i] = s;
+  }
+}
+
+// Block-wide sum of NV per-thread doubles; result atomically added to this block's replica of dst.
 // smem: at least NV * (blockDim.x/64) doubles.  All threads must call.
 template <int NV>
-__device__ __forceinline__ void block_atomic_add(const double (&v)[NV], double* dst, double* smem) {
+__device__ __forceinline__ void block_atomic_add(const double (&v)[NV], double* dst_base, int stride, double* smem) {
+  double* dst = dst_base + (blockIdx.x % kStatRep) * stride;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -64,8 +83,8 @@ __device__ __forceinline__ void bn_affine(double sum, double sumsq, double count
 struct EdgeEncParams {      // encoder.edge_mlp: in(1|2) -> 4 -> 4
   const float* w1; const float* b1; const float* g1; const float* bt1;
   const float* w2; const float* b2; const float* g2; const float* bt2;
-  const double* stat_attr;  // f64[kStatAttr]
-  const double* stat_enc2;  // f64[kStatEnc2]
+  const double* stat_attr;  // f64[kStatRep][kAttrStride]
+  const double* stat_enc2;  // f64[kStatRep][kEnc2Stride]
   int fe;                   // edge_in_dim (1 or 2)
 };
 
@@ -95,17 +114,22 @@ __device__ __forceinline__ void moments_affine(const float* w, int in_dim, float
   bn_affine(sum, sumsq, count, gamma, beta, s, t);
 }
 
-// Computed by threads 0..3 of a block into shared memory; `which`: 1 = layer-1 only, 2 = both.
+// Whole block: add up the replicated moments (scratch: kStatAttr + kStatEnc2 doubles of shared memory), then
+// threads 0..3 derive the affines.  `which`: 1 = layer-1 only, 2 = both.  Ends with a barrier.
 __device__ __forceinline__ void edge_enc_affine_to_smem(const EdgeEncParams& p, double count, int which,
-                                                        EdgeEncAffine* out) {
+                                                        EdgeEncAffine* out, double* scratch) {
+  stat_gather(p.stat_attr, kStatAttr, kAttrStride, scratch);
+  if (which >= 2) stat_gather(p.stat_enc2, kStatEnc2, kEnc2Stride, scratch + kStatAttr);
+  __syncthreads();
   const int k = threadIdx.x;
   if (k < 4) {
-    moments_affine(p.w1 + k * p.fe, p.fe, p.b1[k], p.stat_attr, p.stat_attr + 2, count, p.g1[k], p.bt1[k],
+    moments_affine(p.w1 + k * p.fe, p.fe, p.b1[k], scratch, scratch + 2, count, p.g1[k], p.bt1[k],
                    out->s1[k], out->t1[k]);
     if (which >= 2)
-      moments_affine(p.w2 + k * 4, 4, p.b2[k], p.stat_enc2, p.stat_enc2 + 4, count, p.g2[k], p.bt2[k],
+      moments_affine(p.w2 + k * 4, 4, p.b2[k], scratch + kStatAttr, scratch + kStatAttr + 4, count, p.g2[k], p.bt2[k],
                      out->s2[k], out->t2[k]);
   }
+  __syncthreads();
 }
 
 // u = relu(bn1(W1 a + b1)) : hidden layer of the edge encoder

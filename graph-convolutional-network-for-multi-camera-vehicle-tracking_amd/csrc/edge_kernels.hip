@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepParams p) {
       atomicAdd(p.deg + r, len);
     }
   }
-  block_atomic_add<5>(acc, p.stat_attr, red);
+  block_atomic_add<5>(acc, p.stat_attr, kAttrStride, red);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -67,8 +67,7 @@ __global__ __launch_bounds__(256) void enc2_kernel(EdgeEncParams enc, const floa
                                                    double e_total, double* stat_enc2) {
   __shared__ EdgeEncAffine af;
   __shared__ double red[14 * 4];
-  edge_enc_affine_to_smem(enc, e_total, 1, &af);
-  __syncthreads();
+  edge_enc_affine_to_smem(enc, e_total, 1, &af, red);
   double acc[14];
 #pragma unroll
   for (int i = 0; i < 14; ++i) acc[i] = 0;
@@ -84,7 +83,7 @@ __global__ __launch_bounds__(256) void enc2_kernel(EdgeEncParams enc, const floa
       for (int j = i; j < 4; ++j) acc[4 + tri(4, i, j)] += (double)u[i] * u[j];
     }
   }
-  block_atomic_add<14>(acc, stat_enc2, red);
+  block_atomic_add<14>(acc, stat_enc2, kEnc2Stride, red);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -142,8 +141,7 @@ __device__ __forceinline__ void edge_z1(const RoundParams& p, const EdgeEncAffin
 __global__ __launch_bounds__(256) void pass_a_kernel(RoundParams p) {
   __shared__ EdgeEncAffine af;
   __shared__ double red[8 * 4];
-  if (p.first_round || p.reattach_edges) edge_enc_affine_to_smem(p.enc, p.e_total, 2, &af);
-  __syncthreads();
+  if (p.first_round || p.reattach_edges) edge_enc_affine_to_smem(p.enc, p.e_total, 2, &af, red);
   EdgeUpdWeights w;
   load_edge_upd_weights(p, w);
   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -158,17 +156,19 @@ __global__ __launch_bounds__(256) void pass_a_kernel(RoundParams p) {
       acc[4 + k] += (double)z[k] * z[k];
     }
   }
-  block_atomic_add<8>(acc, p.stats + kRoundZ1, red);
+  block_atomic_add<8>(acc, p.stats + kRoundZ1, kRoundStride, red);
 }
 
 __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
   __shared__ EdgeEncAffine af;
   __shared__ float s1[4], t1[4];
   __shared__ double red[14 * 4];
-  if (p.first_round || p.reattach_edges) edge_enc_affine_to_smem(p.enc, p.e_total, 2, &af);
+  if (p.first_round || p.reattach_edges) edge_enc_affine_to_smem(p.enc, p.e_total, 2, &af, red);
+  stat_gather(p.stats + kRoundZ1, 8, kRoundStride, red);
+  __syncthreads();
   if (threadIdx.x < 4) {
     const int k = threadIdx.x;
-    bn_affine(p.stats[kRoundZ1 + k], p.stats[kRoundZ1 + 4 + k], p.e_total, p.ue_g[k], p.ue_bt[k], s1[k], t1[k]);
+    bn_affine(red[k], red[4 + k], p.e_total, p.ue_g[k], p.ue_bt[k], s1[k], t1[k]);
   }
   __syncthreads();
   EdgeUpdWeights w;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
       for (int k = 0; k < 4; ++k) unsafeAtomicAdd(p.seg + (int64_t)r * 4 + k, (double)v[k]);
     }
   }
-  block_atomic_add<14>(acc, p.stats + kRoundM1, red);
+  block_atomic_add<14>(acc, p.stats + kRoundM1, kRoundStride, red);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -239,14 +239,17 @@ __device__ __forceinline__ void flush_node(const RoundParams& p, int node, int k
 __global__ __launch_bounds__(256) void pass_c_kernel(RoundParams p) {
   __shared__ float4 tile_e[kTileC];
   __shared__ int tile_row[kTileC];
+  __shared__ double st[kRoundStats - kRoundM2];   // e' second moments (10) | z2 sums (32) | z2 sums of squares (32)
   const int k = threadIdx.x & 31;          // channel
   const int hw = threadIdx.x >> 5;         // half-wave 0..7
   // BatchNorm affine of channel k of z2 from the moment statistics (node_stat_kernel + pass B)
+  stat_gather(p.stats + kRoundM2, kRoundStats - kRoundM2, kRoundStride, st);
+  __syncthreads();
   float sk, tk;
   {
     const float* a = p.un_w + k * p.un_ld + p.un_eoff;
-    const double quad = quad_form(a, 4, p.stats + kRoundM2);
-    bn_affine(p.stats[kRoundZ2 + k], p.stats[kRoundZ2 + 32 + k] + quad, p.e_total, p.un_g[k], p.un_bt[k], sk, tk);
+    const double quad = quad_form(a, 4, st);
+    bn_affine(st[kRoundZ2 - kRoundM2 + k], st[kRoundZ2 - kRoundM2 + 32 + k] + quad, p.e_total, p.un_g[k], p.un_bt[k], sk, tk);
   }
   float a4[4];
 #pragma unroll
@@ -300,8 +303,8 @@ __global__ __launch_bounds__(256) void classify_e0_kernel(EdgeEncParams enc, con
                                                           double e_total, const float* cls_w, const float* cls_b,
                                                           int n_classes, float* logits) {
   __shared__ EdgeEncAffine af;
-  edge_enc_affine_to_smem(enc, e_total, 2, &af);
-  __syncthreads();
+  __shared__ double scratch[kStatAttr + kStatEnc2];
+  edge_enc_affine_to_smem(enc, e_total, 2, &af, scratch);
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += nthreads) {
     float a0, a1, u[4], e0[4];

@@ -5,6 +5,7 @@ with ONE library call.  PyTorch is used for device memory and streams only.
 from __future__ import annotations
 
 import ctypes as C
+import types
 from typing import List, Tuple
 
 import torch
@@ -89,7 +90,8 @@ class ForwardEngine:
         if edge_index.dtype != torch.int64:
             raise RuntimeError("mtmc_mpn: edge_index must be int64")
 
-    def __call__(self, x, edge_index, edge_attr, training=False) -> Tuple[List[torch.Tensor], torch.Tensor]:
+    def prepare(self, x, edge_index, edge_attr, training=False, n_edges_total=None, node_range=None):
+        """Validate, allocate outputs/workspace and fill the two C structs of one call."""
         self.check_inputs(x, edge_index, edge_attr)
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.module.parameters())):
             raise NotImplementedError(
@@ -98,41 +100,76 @@ class ForwardEngine:
         if training:
             raise NotImplementedError("mtmc_mpn: training-mode forward (Dropout masks) is not built yet; use .eval()")
         s, dev = self.spec, x.device
-        n, e = x.shape[0], edge_index.shape[1]
+        e = edge_index.shape[1]
+        node_lo, node_hi = (0, x.shape[0]) if node_range is None else node_range[:2]
+        n = x.shape[0] if node_range is None else node_range[2]
         if x.stride(1) != 1 or x.stride(0) % 4 != 0:
             x = x.contiguous()
         if not edge_attr.is_contiguous():
             edge_attr = edge_attr.contiguous()
         if e > 0 and edge_index.stride(1) < 1:
             edge_index = edge_index.contiguous()
-        n_out = s.num_class_steps if s.num_enc_steps > 0 else 1
-        n_out = min(n_out, max(s.num_enc_steps, 1))
+        n_out = min(s.num_class_steps, s.num_enc_steps) if s.num_enc_steps > 0 else 1
         n_cls = s.cls_edge[0].out_dim
         logits = torch.empty((n_out, e, n_cls), dtype=torch.float32, device=dev)
         h = torch.empty((n, s.node_dim), dtype=torch.float32, device=dev)
-
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            model = self.model_struct(dev)
-            ws = self.workspace(model, n, e, dev, stream)
-            call = _lib.Call()
-            call.x, call.x_row_stride = x.data_ptr(), x.stride(0)
-            call.row = edge_index[0].data_ptr() if e > 0 else None
-            call.col = edge_index[1].data_ptr() if e > 0 else None
-            call.idx_stride = edge_index.stride(1) if e > 0 else 1
-            call.edge_attr = edge_attr.data_ptr() if e > 0 else ws.data_ptr()
-            call.n_nodes, call.n_edges, call.n_edges_total = n, e, e
-            call.node_lo, call.node_hi = 0, n
-            call.logits = logits.data_ptr() if logits.numel() else ws.data_ptr()
-            call.h_out = h.data_ptr()
-            call.workspace, call.workspace_bytes = ws.data_ptr(), ws.numel()
-            call.training, call.flags, call.seed = 0, 0, 0
-            call.stream = stream
-            _lib.check(self.lib.mtmc_mpn_forward(C.byref(model), C.byref(call)))
+        model = self.model_struct(dev)
+        ws = self.workspace(model, n, e, dev, stream)
+        call = _lib.Call()
+        call.x, call.x_row_stride = x.data_ptr(), x.stride(0)
+        call.row = edge_index[0].data_ptr() if e > 0 else None
+        call.col = edge_index[1].data_ptr() if e > 0 else None
+        call.idx_stride = edge_index.stride(1) if e > 0 else 1
+        call.edge_attr = edge_attr.data_ptr() if e > 0 else ws.data_ptr()
+        call.n_nodes, call.n_edges = n, e
+        call.n_edges_total = e if n_edges_total is None else n_edges_total
+        call.node_lo, call.node_hi = node_lo, node_hi
+        call.logits = logits.data_ptr() if logits.numel() else ws.data_ptr()
+        call.h_out = h.data_ptr()
+        call.workspace, call.workspace_bytes = ws.data_ptr(), ws.numel()
+        call.training, call.flags, call.seed = 0, 0, 0
+        call.stream = stream
+        keep = (x, edge_index, edge_attr)        # the structs hold raw pointers: keep the tensors alive
+        return types.SimpleNamespace(model=model, call=call, ws=ws, logits=logits, h=h, n_out=n_out, n=n, e=e,
+                                     dev=dev, keep=keep)
+
+    def phase_list(self):
+        """(phase, arg) pairs of one forward, in order (what mtmc_mpn_forward runs internally)."""
+        s = self.spec
+        seq = [(_lib.PH_BEGIN, 0), (_lib.PH_EDGE_ENC, 0)]
+        seq += [(_lib.PH_NODE_ENC, l) for l in range(len(s.enc_node))]
+        seq += [(_lib.PH_NODE_H0, 0)]
+        for r in range(s.num_enc_steps):
+            seq += [(_lib.PH_ROUND_PROJ, r), (_lib.PH_ROUND_A, r), (_lib.PH_ROUND_B, r), (_lib.PH_ROUND_STAT, r),
+                    (_lib.PH_ROUND_C, r)]
+        return seq + [(_lib.PH_END, 0)]
+
+    def layout(self, prep) -> _lib.WsLayout:
+        lay = _lib.WsLayout()
+        _lib.check(self.lib.mtmc_mpn_workspace_layout(C.byref(prep.model), prep.n, prep.e, C.byref(lay)))
+        return lay
+
+    def run_phases(self, prep, after_phase=None, before_phase=None):
+        """Phase-by-phase forward (same kernels as __call__): the multi-GPU host interleaves collectives
+        through `after_phase(phase, arg)`, bench.py brackets phases with events."""
+        with torch.cuda.device(prep.dev):
+            for ph, arg in self.phase_list():
+                if before_phase is not None:
+                    before_phase(ph, arg)
+                _lib.check(self.lib.mtmc_mpn_run_phase(C.byref(prep.model), C.byref(prep.call), ph, arg))
+                if after_phase is not None:
+                    after_phase(ph, arg)
+        return [prep.logits[i] for i in range(prep.n_out)], prep.h
+
+    def __call__(self, x, edge_index, edge_attr, training=False) -> Tuple[List[torch.Tensor], torch.Tensor]:
+        prep = self.prepare(x, edge_index, edge_attr, training)
+        with torch.cuda.device(prep.dev):
+            _lib.check(self.lib.mtmc_mpn_forward(C.byref(prep.model), C.byref(prep.call)))
             if self.module.check_indices:
-                lay = _lib.WsLayout()
-                _lib.check(self.lib.mtmc_mpn_workspace_layout(C.byref(model), n, e, C.byref(lay)))
-                flags = ws[lay.flags_off:lay.flags_off + 32].view(torch.int32).cpu()
+                lay = self.layout(prep)
+                flags = prep.ws[lay.flags_off:lay.flags_off + 32].view(torch.int32).cpu()
                 if int(flags[1]) != 0:
                     raise IndexError("mtmc_mpn: edge_index holds node ids outside [0, N)")
-        return [logits[i] for i in range(n_out)], h
+        return [prep.logits[i] for i in range(prep.n_out)], prep.h
