@@ -3,6 +3,7 @@
 // so a caller may capture a forward into a hipGraph.
 #include "kernels.h"
 
+#include <mutex>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -24,7 +25,7 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 struct Layout {
   mtmc_ws_layout pub;
-  size_t row32, col32, e_buf, P, Q;
+  size_t row32, col32, e_buf, P, Q, slab, enc_aff;
   size_t Y[MTMC_MAX_ENC_LAYERS];
   size_t stat_enc_layer[MTMC_MAX_ENC_LAYERS];
 };
@@ -78,12 +79,21 @@ void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* lo) {
   lo->pub.h0_off = take((size_t)N * 32 * sizeof(float));
   lo->pub.h_acc_off[0] = take((size_t)N * 32 * sizeof(float));
   lo->pub.h_acc_off[1] = take((size_t)N * 32 * sizeof(float));
+  lo->enc_aff = take(16 * sizeof(float));
   lo->P = take((size_t)N * 8 * sizeof(float));
   lo->Q = take((size_t)N * 32 * sizeof(float));
   lo->row32 = take((size_t)E * sizeof(int32_t));
   lo->col32 = take((size_t)E * sizeof(int32_t));
   lo->e_buf = take((size_t)E * 4 * sizeof(float));
   for (int l = 0; l < m->n_enc_layers; ++l) lo->Y[l] = take((size_t)N * m->enc_node[l].out_dim * sizeof(float));
+  size_t slab = 0;                                 // split-K scratch of the node encoder (few-row graphs only)
+  for (int l = 0; l < m->n_enc_layers; ++l) {
+    int sk;
+    mtmc::gemm_plan(N, m->enc_node[l].in_dim, m->enc_node[l].out_dim, &sk);
+    const size_t need = sk > 1 ? (size_t)sk * N * m->enc_node[l].out_dim * sizeof(float) : 0;
+    if (need > slab) slab = need;
+  }
+  lo->slab = take(slab);
   lo->pub.total_bytes = off;
 }
 
@@ -130,8 +140,15 @@ mtmc::EdgeEncParams enc_params(const Ctx& x) {
   e.w2 = b.weight; e.b2 = b.bias; e.g2 = b.gamma; e.bt2 = b.beta;
   e.stat_attr = x.at<double>(x.lo.pub.stat_attr_off);
   e.stat_enc2 = x.at<double>(x.lo.pub.stat_enc2_off);
+  e.aff = x.at<float>(x.lo.enc_aff);
   e.fe = a.in_dim;
   return e;
+}
+
+// Where round r aggregates: the last round of a sum/max model writes latent_node_feats straight into h_out.
+float* agg_target(const Ctx& x, int r) {
+  if (r == x.m->num_enc_steps - 1 && x.m->agg != MTMC_AGG_MEAN) return x.c->h_out;
+  return x.at<float>(x.lo.pub.h_acc_off[r & 1]);
 }
 
 mtmc::RoundParams round_params(const Ctx& x, int r) {
@@ -148,7 +165,7 @@ mtmc::RoundParams round_params(const Ctx& x, int r) {
   p.cls_w = m->cls.weight; p.cls_b = m->cls.bias; p.n_classes = m->cls.out_dim;
   p.stats = x.at<double>(x.lo.pub.stat_round_off) + (size_t)r * mtmc::kStatRep * mtmc::kRoundStride;
   p.seg = x.at<double>(x.lo.pub.seg_off);
-  p.h_acc = x.at<float>(x.lo.pub.h_acc_off[r & 1]);
+  p.h_acc = agg_target(x, r);
   const int step = r + 1;
   int first_cls = m->num_enc_steps - m->num_class_steps + 1;   // mpn.py:277; Cs > L classifies every round
   if (first_cls < 1) first_cls = 1;
@@ -159,15 +176,20 @@ mtmc::RoundParams round_params(const Ctx& x, int r) {
   return p;
 }
 
-int run_phase(const Ctx& x, int phase, int arg) {
+enum { kPhMemset = -1, kPhPrep = -2 };   // the two halves of MTMC_PH_BEGIN, for the forked forward
+
+int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
   const mtmc_mpn_model* m = x.m;
   const mtmc_mpn_call* c = x.c;
   const int L = m->num_enc_steps;
   hipStream_t s = x.stream;
   switch (phase) {
-    case MTMC_PH_BEGIN: {
-      if (hipMemsetAsync(x.ws, 0, x.lo.pub.zero_bytes, s) != hipSuccess) return fail(MTMC_E_HIP, "hipMemsetAsync failed");
-      if (c->n_edges > 0) {
+    case MTMC_PH_BEGIN:
+    case kPhMemset:
+    case kPhPrep: {
+      if (phase != kPhPrep && hipMemsetAsync(x.ws, 0, x.lo.pub.zero_bytes, s) != hipSuccess)
+        return fail(MTMC_E_HIP, "hipMemsetAsync failed");
+      if (phase != kPhMemset && c->n_edges > 0) {
         mtmc::PrepParams p;
         p.row = c->row; p.col = c->col; p.idx_stride = c->idx_stride; p.attr = c->edge_attr; p.fe = m->enc_edge[0].in_dim;
         p.n_edges = c->n_edges; p.n_nodes = c->n_nodes;
@@ -197,6 +219,14 @@ int run_phase(const Ctx& x, int phase, int arg) {
       g.W = Lr.weight; g.bias = Lr.bias; g.Y = x.at<float>(x.lo.Y[arg]); g.ldy = Lr.out_dim;
       g.count = (double)c->n_nodes; g.stats_out = x.at<double>(x.lo.stat_enc_layer[arg]);
       g.M = rows; g.K = Lr.in_dim; g.Nout = Lr.out_dim;
+      {  // the slab was sized for N rows; a shard with fewer rows may plan a larger split
+        int sk_full, sk_here;
+        mtmc::gemm_plan(c->n_nodes, g.K, g.Nout, &sk_full);
+        mtmc::gemm_plan(rows, g.K, g.Nout, &sk_here);
+        g.slab = (sk_here > 1 && (size_t)sk_here * rows <= (size_t)(sk_full > 1 ? sk_full : 0) * c->n_nodes)
+                     ? x.at<float>(x.lo.slab) : nullptr;
+        g.split_k = 1;
+      }
       if (mtmc::launch_gemm_bn(g, s) != MTMC_OK) return fail(MTMC_E_ARG, "encoder layer %d: unsupported GEMM shape", arg);
       break;
     }
@@ -212,6 +242,11 @@ int run_phase(const Ctx& x, int phase, int arg) {
     case MTMC_PH_ROUND_PROJ: {
       if (arg < 0 || arg >= L) return fail(MTMC_E_ARG, "round %d out of range", arg);
       mtmc::NodeProjParams p;
+      const int last = m->n_enc_layers - 1;
+      p.y_last = (arg == 0 && fused_h0) ? x.at<float>(x.lo.Y[last]) : nullptr;
+      p.y_stats = x.at<double>(x.lo.stat_enc_layer[last]); p.y_gamma = m->enc_node[last].gamma;
+      p.y_beta = m->enc_node[last].beta; p.y_count = (double)c->n_nodes; p.h0_out = x.at<float>(x.lo.pub.h0_off);
+      p.finalize_enc = arg == 0; p.enc = enc_params(x); p.e_total = (double)c->n_edges_total;
       p.h_src = arg == 0 ? x.at<float>(x.lo.pub.h0_off) : x.at<float>(x.lo.pub.h_acc_off[(arg - 1) & 1]);
       p.h0 = m->reattach_nodes ? x.at<float>(x.lo.pub.h0_off) : nullptr;
       p.deg = (m->agg == MTMC_AGG_MEAN && arg > 0) ? x.at<int>(x.lo.pub.deg_off) : nullptr;
@@ -219,7 +254,7 @@ int run_phase(const Ctx& x, int phase, int arg) {
       p.un_w = m->upd_node.weight; p.un_ld = m->upd_node.in_dim;
       p.hn = (m->reattach_nodes ? 2 : 1) * MTMC_NODE_DIM;
       p.P = x.at<float>(x.lo.P); p.Q = x.at<float>(x.lo.Q);
-      p.zero_buf = x.at<float>(x.lo.pub.h_acc_off[arg & 1]);
+      p.zero_buf = agg_target(x, arg);
       p.n_nodes = c->n_nodes;
       mtmc::launch_node_proj(p, s);
       break;
@@ -248,7 +283,8 @@ int run_phase(const Ctx& x, int phase, int arg) {
     }
     case MTMC_PH_END: {
       const float* src = L == 0 ? x.at<float>(x.lo.pub.h0_off) : x.at<float>(x.lo.pub.h_acc_off[(L - 1) & 1]);
-      mtmc::launch_h_final(src, x.at<int>(x.lo.pub.deg_off), (m->agg == MTMC_AGG_MEAN && L > 0) ? 1 : 0, c->n_nodes, c->h_out, s);
+      if (L == 0 || m->agg == MTMC_AGG_MEAN)     // otherwise the last round already aggregated into h_out
+        mtmc::launch_h_final(src, x.at<int>(x.lo.pub.deg_off), (m->agg == MTMC_AGG_MEAN && L > 0) ? 1 : 0, c->n_nodes, c->h_out, s);
       if (L == 0 && c->n_edges > 0)
         mtmc::launch_classify_e0(enc_params(x), c->edge_attr, c->n_edges, (double)c->n_edges_total, m->cls.weight,
                                  m->cls.bias, m->cls.out_dim, c->logits, s);
@@ -260,6 +296,28 @@ int run_phase(const Ctx& x, int phase, int arg) {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MTMC_E_HIP, "kernel launch failed in phase %d: %s", phase, hipGetErrorString(e));
   return MTMC_OK;
+}
+
+// The edge branch (index conversion, degree, edge-encoder moments) and the node-encoder GEMM chain are
+// independent until the first round.  With MTMC_F_FORK the edge branch runs on a side stream (fork/join with
+// events; legal under stream capture too).  Opt-in: measured on MI355X/ROCm 7.2 the two event hops cost more
+// (~+20 us per forward on the 150k-edge S02 graph) than the ~17 us of overlap they buy.
+// One side stream + event pair per device, created on first use.
+struct Side { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; };
+Side* side_for_current_device() {
+  static Side sides[64];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  Side& sd = sides[dev];
+  if (!sd.ok) {
+    if (hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    sd.ok = true;
+  }
+  return &sd;
 }
 
 }  // namespace
@@ -295,13 +353,28 @@ int32_t mtmc_mpn_forward(const mtmc_mpn_model* model, const mtmc_mpn_call* call)
   Ctx x;
   if (int rc = make_ctx(model, call, &x)) return rc;
   int rc;
-  if ((rc = run_phase(x, MTMC_PH_BEGIN, 0))) return rc;
-  if ((rc = run_phase(x, MTMC_PH_EDGE_ENC, 0))) return rc;
+  Side* sd = (call->flags & MTMC_F_FORK) ? side_for_current_device() : nullptr;
+  if (sd) {
+    if ((rc = run_phase(x, kPhMemset, 0))) return rc;
+    if (hipEventRecord(sd->fork, x.stream) != hipSuccess || hipStreamWaitEvent(sd->stream, sd->fork, 0) != hipSuccess)
+      return fail(MTMC_E_HIP, "fork onto the side stream failed");
+    Ctx xs = x;
+    xs.stream = sd->stream;
+    if ((rc = run_phase(xs, kPhPrep, 0))) return rc;
+    if ((rc = run_phase(xs, MTMC_PH_EDGE_ENC, 0))) return rc;
+    if (hipEventRecord(sd->join, sd->stream) != hipSuccess) return fail(MTMC_E_HIP, "hipEventRecord failed");
+  } else {
+    if ((rc = run_phase(x, MTMC_PH_BEGIN, 0))) return rc;
+    if ((rc = run_phase(x, MTMC_PH_EDGE_ENC, 0))) return rc;
+  }
   for (int l = 0; l < model->n_enc_layers; ++l)
     if ((rc = run_phase(x, MTMC_PH_NODE_ENC, l))) return rc;
-  if ((rc = run_phase(x, MTMC_PH_NODE_H0, 0))) return rc;
+  if (sd && hipStreamWaitEvent(x.stream, sd->join, 0) != hipSuccess) return fail(MTMC_E_HIP, "join failed");
+  // single shard: h0 = relu(bn(Y_last)) is produced inside the first round's projection kernel
+  const bool fused_h0 = model->num_enc_steps > 0 && call->node_lo == 0 && call->node_hi == call->n_nodes;
+  if (!fused_h0 && (rc = run_phase(x, MTMC_PH_NODE_H0, 0))) return rc;
   for (int r = 0; r < model->num_enc_steps; ++r) {
-    if ((rc = run_phase(x, MTMC_PH_ROUND_PROJ, r))) return rc;
+    if ((rc = run_phase(x, MTMC_PH_ROUND_PROJ, r, fused_h0))) return rc;
     if ((rc = run_phase(x, MTMC_PH_ROUND_A, r))) return rc;
     if ((rc = run_phase(x, MTMC_PH_ROUND_B, r))) return rc;
     if ((rc = run_phase(x, MTMC_PH_ROUND_STAT, r))) return rc;
@@ -346,6 +419,7 @@ int32_t mtmc_mlp_layer_forward(const mtmc_layer* layer, const float* x, int64_t 
   g.A = x; g.lda = x_row_stride; g.W = layer->weight; g.bias = layer->bias; g.Y = y; g.ldy = layer->out_dim;
   g.stats_in = nullptr; g.gamma_in = nullptr; g.beta_in = nullptr; g.count = (double)rows;
   g.stats_out = bn ? stats_scratch : nullptr; g.M = rows; g.K = layer->in_dim; g.Nout = layer->out_dim;
+  g.slab = nullptr; g.split_k = 1;
   if (mtmc::launch_gemm_bn(g, s) != MTMC_OK) return fail(MTMC_E_ARG, "unsupported layer shape");
   if (bn) mtmc::launch_bn_relu_rows(y, layer->out_dim, rows, layer->out_dim, stats_scratch, layer->gamma, layer->beta, (double)rows, y, s);
   const hipError_t e = hipGetLastError();

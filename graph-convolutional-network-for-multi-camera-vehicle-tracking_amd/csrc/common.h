@@ -69,14 +69,19 @@ __device__ __forceinline__ void block_atomic_add(const double (&v)[NV], double* 
 }
 
 // BatchNorm (batch statistics) as y = s*z + t from fp64 (sum, sumsq) over `count` rows.
+// Latency matters (this sits in kernel prologues): no fp64 division or square root -- multiply by 1/count,
+// take v_rsq_f32 of the variance and polish it with one fp64 Newton step (error ~1e-14 relative).
 __device__ __forceinline__ void bn_affine(double sum, double sumsq, double count, float gamma, float beta,
                                           float& s, float& t) {
-  const double mean = sum / count;
-  double var = sumsq / count - mean * mean;
-  var = var < 0 ? 0 : var;
-  const double sd = (double)gamma / sqrt(var + MTMC_BN_EPS);
+  const double inv = 1.0 / count;            // count is a kernel argument: uniform, hoisted by the compiler
+  const double mean = sum * inv;
+  double var = fma(sumsq, inv, -mean * mean);
+  var = (var < 0 ? 0 : var) + MTMC_BN_EPS;
+  double r = (double)rsqrtf((float)var);
+  r = r * fma(-0.5 * var, r * r, 1.5);
+  const double sd = (double)gamma * r;
   s = (float)sd;
-  t = (float)((double)beta - mean * sd);
+  t = (float)fma(-mean, sd, (double)beta);
 }
 
 // Small per-launch parameter blocks, read through uniform (scalar) loads.
@@ -85,6 +90,7 @@ struct EdgeEncParams {      // encoder.edge_mlp: in(1|2) -> 4 -> 4
   const float* w2; const float* b2; const float* g2; const float* bt2;
   const double* stat_attr;  // f64[kStatRep][kAttrStride]
   const double* stat_enc2;  // f64[kStatRep][kEnc2Stride]
+  float* aff;               // f32[16] = EdgeEncAffine, finalised once per forward by node_proj_kernel (round 0)
   int fe;                   // edge_in_dim (1 or 2)
 };
 
@@ -129,6 +135,12 @@ __device__ __forceinline__ void edge_enc_affine_to_smem(const EdgeEncParams& p, 
       moments_affine(p.w2 + k * 4, 4, p.b2[k], scratch + kStatAttr, scratch + kStatAttr + 4, count, p.g2[k], p.bt2[k],
                      out->s2[k], out->t2[k]);
   }
+  __syncthreads();
+}
+
+// Passes A/B: the affines were finalised once (EdgeEncParams::aff); fetch the 16 floats.  Ends with a barrier.
+__device__ __forceinline__ void edge_enc_affine_load(const EdgeEncParams& p, EdgeEncAffine* out) {
+  if (threadIdx.x < 16) reinterpret_cast<float*>(out)[threadIdx.x] = p.aff[threadIdx.x];
   __syncthreads();
 }
 

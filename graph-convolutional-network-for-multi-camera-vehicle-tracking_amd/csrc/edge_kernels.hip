@@ -138,23 +138,36 @@ __device__ __forceinline__ void edge_z1(const RoundParams& p, const EdgeEncAffin
   }
 }
 
+constexpr int kEPT = 4;   // edges per thread and loop trip in passes A/B: four independent load chains in flight
+
 __global__ __launch_bounds__(256) void pass_a_kernel(RoundParams p) {
   __shared__ EdgeEncAffine af;
   __shared__ double red[8 * 4];
-  if (p.first_round || p.reattach_edges) edge_enc_affine_to_smem(p.enc, p.e_total, 2, &af, red);
+  if (p.first_round || p.reattach_edges) edge_enc_affine_load(p.enc, &af);
   EdgeUpdWeights w;
   load_edge_upd_weights(p, w);
   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < p.n_edges; e += nthreads) {
-    int r;
-    float z[4];
-    edge_z1(p, af, w, e, r, z);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * kEPT;
+  for (int64_t base = (int64_t)blockIdx.x * blockDim.x * kEPT + threadIdx.x; base < p.n_edges; base += stride) {
+    float z[kEPT][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      acc[k] += z[k];
-      acc[4 + k] += (double)z[k] * z[k];
+    for (int i = 0; i < kEPT; ++i) {
+      const int64_t e = base + i * 256;
+      int r;
+      if (e < p.n_edges) {
+        edge_z1(p, af, w, e, r, z[i]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) z[i][k] = 0.f;
+      }
     }
+#pragma unroll
+    for (int i = 0; i < kEPT; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc[k] += z[i][k];
+        acc[4 + k] += (double)z[i][k] * z[i][k];
+      }
   }
   block_atomic_add<8>(acc, p.stats + kRoundZ1, kRoundStride, red);
 }
@@ -163,9 +176,8 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
   __shared__ EdgeEncAffine af;
   __shared__ float s1[4], t1[4];
   __shared__ double red[14 * 4];
-  if (p.first_round || p.reattach_edges) edge_enc_affine_to_smem(p.enc, p.e_total, 2, &af, red);
   stat_gather(p.stats + kRoundZ1, 8, kRoundStride, red);
-  __syncthreads();
+  if (p.first_round || p.reattach_edges) edge_enc_affine_load(p.enc, &af); else __syncthreads();
   if (threadIdx.x < 4) {
     const int k = threadIdx.x;
     bn_affine(red[k], red[4 + k], p.e_total, p.ue_g[k], p.ue_bt[k], s1[k], t1[k]);
@@ -177,46 +189,60 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
 #pragma unroll
   for (int i = 0; i < 14; ++i) acc[i] = 0;
   const int lane = threadIdx.x & 63;
-  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * kEPT;
   const int64_t e_end = ((p.n_edges + 63) / 64) * 64;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < e_end; e += nthreads) {
-    const bool active = e < p.n_edges;
-    int r = -1;
-    float v[4] = {0, 0, 0, 0};
-    if (active) {
-      float z[4];
-      edge_z1(p, af, w, e, r, z);
+  for (int64_t base = (int64_t)blockIdx.x * blockDim.x * kEPT + threadIdx.x; base < e_end; base += stride) {
+    int rr[kEPT];
+    float vv[kEPT][4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = fmaxf(fmaf(z[k], s1[k], t1[k]), 0.f);
-      reinterpret_cast<float4*>(p.e_buf)[e] = make_float4(v[0], v[1], v[2], v[3]);
+    for (int i = 0; i < kEPT; ++i) {
+      const int64_t e = base + i * 256;
+      rr[i] = -1;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        acc[i] += v[i];
+      for (int k = 0; k < 4; ++k) vv[i][k] = 0.f;
+      if (e < p.n_edges) {
+        float z[4];
+        edge_z1(p, af, w, e, rr[i], z);
 #pragma unroll
-        for (int j = i; j < 4; ++j) acc[4 + tri(4, i, j)] += (double)v[i] * v[j];
+        for (int k = 0; k < 4; ++k) vv[i][k] = fmaxf(fmaf(z[k], s1[k], t1[k]), 0.f);
+        reinterpret_cast<float4*>(p.e_buf)[e] = make_float4(vv[i][0], vv[i][1], vv[i][2], vv[i][3]);
       }
     }
-    // per-node segment sums S[row] += e': segmented inclusive scan over the wave (any row order),
-    // then one fp64 atomic per run and channel
-    const int prev = __shfl_up(r, 1, 64);
-    int flag = (lane == 0 || prev != r) ? 1 : 0;
-    const int next_head = __shfl_down(flag, 1, 64);
-    const bool tail = active && (lane == 63 || next_head != 0 || e + 1 >= p.n_edges);
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int f_up = __shfl_up(flag, off, 64);
-      float u[4];
+    for (int i = 0; i < kEPT; ++i) {
+      const int64_t e = base + i * 256;
+      if (e - lane >= p.n_edges) continue;         // whole wave past the end (wave-uniform)
+      const bool active = e < p.n_edges;
+      float* v = vv[i];
+      const int r = rr[i];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) u[k] = __shfl_up(v[k], off, 64);
-      if (lane >= off && !flag) {
+      for (int a = 0; a < 4; ++a) {
+        acc[a] += v[a];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] += u[k];
-        flag = f_up;
+        for (int b = a; b < 4; ++b) acc[4 + tri(4, a, b)] += (double)v[a] * v[b];
       }
-    }
-    if (tail) {
+      // per-node segment sums S[row] += e': segmented inclusive scan over the wave (any row order),
+      // then one fp64 atomic per run and channel
+      const int prev = __shfl_up(r, 1, 64);
+      int flag = (lane == 0 || prev != r) ? 1 : 0;
+      const int next_head = __shfl_down(flag, 1, 64);
+      const bool tail = active && (lane == 63 || next_head != 0 || e + 1 >= p.n_edges);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) unsafeAtomicAdd(p.seg + (int64_t)r * 4 + k, (double)v[k]);
+      for (int off = 1; off < 64; off <<= 1) {
+        const int f_up = __shfl_up(flag, off, 64);
+        float u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u[k] = __shfl_up(v[k], off, 64);
+        if (lane >= off && !flag) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] += u[k];
+          flag = f_up;
+        }
+      }
+      if (tail) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) unsafeAtomicAdd(p.seg + (int64_t)r * 4 + k, (double)v[k]);
+      }
     }
   }
   block_atomic_add<14>(acc, p.stats + kRoundM1, kRoundStride, red);
@@ -337,10 +363,10 @@ void launch_enc2(const EdgeEncParams& enc, const float* attr, int64_t n_edges, d
                      stat_enc2);
 }
 void launch_pass_a(const RoundParams& p, hipStream_t s) {
-  hipLaunchKernelGGL(pass_a_kernel, dim3(edge_grid(p.n_edges, 256)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(pass_a_kernel, dim3(edge_grid(p.n_edges, 256 * kEPT)), dim3(256), 0, s, p);
 }
 void launch_pass_b(const RoundParams& p, hipStream_t s) {
-  hipLaunchKernelGGL(pass_b_kernel, dim3(edge_grid(p.n_edges, 256)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(pass_b_kernel, dim3(edge_grid(p.n_edges, 256 * kEPT)), dim3(256), 0, s, p);
 }
 void launch_pass_c(const RoundParams& p, hipStream_t s) {
   hipLaunchKernelGGL(pass_c_kernel, dim3(edge_grid(p.n_edges, kTileC)), dim3(256), 0, s, p);

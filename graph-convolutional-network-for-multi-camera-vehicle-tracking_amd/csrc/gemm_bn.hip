@@ -21,18 +21,21 @@ namespace mtmc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;
-constexpr int LDK = BK + 4;
-
-template <int TM, int TN>
+// BK = 32 for the big-tile configuration (LDS budget), 64 for the few-row split-K configuration, where the
+// k-loop is a chain of dependent HBM/L2 round trips and a deeper tile halves their number.
+template <int TM, int TN, int BK>
 __global__ __launch_bounds__(256) void gemm_bn_kernel(GemmParams p, int tiles_m, int tiles_n) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
-  constexpr int A4 = BM / 32, B4 = BN / 32;          // float4 loads per thread per k-tile
+  constexpr int LDK = BK + 4;                        // row stride 144 B / 272 B: conflict-free ds_read_b128
+  constexpr int C4 = BK / 4;                         // float4 per tile row
+  constexpr int A4 = BM * C4 / 256, B4 = BN * C4 / 256;   // float4 loads per thread per k-tile
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                                   // [BM][LDK]
   float* Bs = smem + BM * LDK;                        // [BN][LDK]
-  float* s_in = Bs + BN * LDK;                        // [K]
-  float* t_in = s_in + p.K;                           // [K]
+  const int kc = p.K / p.split_k;                     // this block's share of K (split-K along blockIdx.y)
+  const int k_base = blockIdx.y * kc;
+  float* s_in = Bs + BN * LDK;                        // [kc]
+  float* t_in = s_in + kc;                            // [kc]
 
   // XCD-aware tile order: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch); give each XCD
   // whole row panels so the A panel is re-read from its own L2 by the panel's column tiles.
@@ -44,8 +47,9 @@ __global__ __launch_bounds__(256) void gemm_bn_kernel(GemmParams p, int tiles_m,
 
   const bool act = p.stats_in != nullptr;
   if (act) {
-    for (int kk = threadIdx.x; kk < p.K; kk += 256)
-      bn_affine(p.stats_in[kk], p.stats_in[p.K + kk], p.count, p.gamma_in[kk], p.beta_in[kk], s_in[kk], t_in[kk]);
+    for (int kk = threadIdx.x; kk < kc; kk += 256)
+      bn_affine(p.stats_in[k_base + kk], p.stats_in[p.K + k_base + kk], p.count, p.gamma_in[k_base + kk],
+                p.beta_in[k_base + kk], s_in[kk], t_in[kk]);
   }
 
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -53,17 +57,17 @@ __global__ __launch_bounds__(256) void gemm_bn_kernel(GemmParams p, int tiles_m,
 
   float4 ra[A4], rb[B4];
   auto load_tiles = [&](int kt) {
-    const int k0 = kt * BK;
+    const int k0 = k_base + kt * BK;
 #pragma unroll
     for (int i = 0; i < A4; ++i) {
-      const int f = threadIdx.x + i * 256, r = f >> 3, c4 = f & 7;
+      const int f = threadIdx.x + i * 256, r = f / C4, c4 = f % C4;
       const int64_t row = m0 + r;
       ra[i] = row < p.M ? *reinterpret_cast<const float4*>(p.A + row * p.lda + k0 + c4 * 4)
                         : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < B4; ++i) {
-      const int f = threadIdx.x + i * 256, r = f >> 3, c4 = f & 7;
+      const int f = threadIdx.x + i * 256, r = f / C4, c4 = f % C4;
       const int n = n0 + r;
       rb[i] = n < p.Nout ? *reinterpret_cast<const float4*>(p.W + (int64_t)n * p.K + k0 + c4 * 4)
                          : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(256) void gemm_bn_kernel(GemmParams p, int tiles_m,
     const int k0 = kt * BK;
 #pragma unroll
     for (int i = 0; i < A4; ++i) {
-      const int f = threadIdx.x + i * 256, r = f >> 3, c4 = f & 7;
+      const int f = threadIdx.x + i * 256, r = f / C4, c4 = f % C4;
       float4 v = ra[i];
       if (act) {
         const float4 s = *reinterpret_cast<const float4*>(s_in + k0 + c4 * 4);
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(256) void gemm_bn_kernel(GemmParams p, int tiles_m,
     }
 #pragma unroll
     for (int i = 0; i < B4; ++i) {
-      const int f = threadIdx.x + i * 256, r = f >> 3, c4 = f & 7;
+      const int f = threadIdx.x + i * 256, r = f / C4, c4 = f % C4;
       *reinterpret_cast<float4*>(Bs + r * LDK + c4 * 4) = rb[i];
     }
   };
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void gemm_bn_kernel(GemmParams p, int tiles_m,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = p.K / BK;
+  const int nk = kc / BK;
   load_tiles(0);
   const int a_off = (wm * TM * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
   const int b_off = (wn * TN * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
@@ -128,6 +132,22 @@ __global__ __launch_bounds__(256) void gemm_bn_kernel(GemmParams p, int tiles_m,
     }
   }
 
+  if (p.split_k > 1) {
+    // split-K: plain-store the partial tile into this slice's slab; combine_stats_kernel finishes the layer
+    float* slab = p.slab + (size_t)blockIdx.y * p.M * p.Nout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row < p.M && col < p.Nout) slab[row * p.Nout + col] = acc[i][j][r];
+        }
+    }
+    return;
+  }
   // epilogue: + bias, store raw Y, fp64 column statistics
   __syncthreads();
   double* colred = reinterpret_cast<double*>(smem);   // [2 (wm)][2 (sum,sq)][BN]
@@ -165,6 +185,49 @@ __global__ __launch_bounds__(256) void gemm_bn_kernel(GemmParams p, int tiles_m,
   }
 }
 
+// Second half of a split-K layer: Y = bias + sum of the K-slices' slabs (fixed order => reproducible),
+// and the fp64 column statistics of Y.  Block = 64 columns x kCombRows rows; thread = one column, every 4th row;
+// all of a row's slice loads are issued together (they are independent; only the additions are ordered).
+constexpr int kCombRows = 16;
+constexpr int kMaxSplit = 8;
+
+__global__ __launch_bounds__(256) void combine_stats_kernel(GemmParams p) {
+  __shared__ double red[2 * 4 * 64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  const int64_t r0 = (int64_t)blockIdx.y * kCombRows;
+  const size_t slice = (size_t)p.M * p.Nout;
+  double cs = 0, cq = 0;
+  if (col < p.Nout) {
+    const float bias = p.bias[col];
+#pragma unroll
+    for (int i = 0; i < kCombRows / 4; ++i) {
+      const int64_t row = r0 + rg + 4 * i;
+      if (row < p.M) {
+        float v[kMaxSplit];
+#pragma unroll
+        for (int z = 0; z < kMaxSplit; ++z) v[z] = z < p.split_k ? p.slab[z * slice + row * p.Nout + col] : 0.f;
+        float y = bias;
+#pragma unroll
+        for (int z = 0; z < kMaxSplit; ++z) y += v[z];
+        p.Y[row * p.ldy + col] = y;
+        cs += y;
+        cq += (double)y * y;
+      }
+    }
+  }
+  red[rg * 64 + cl] = cs;
+  red[256 + rg * 64 + cl] = cq;
+  __syncthreads();
+  if (threadIdx.x < 128 && p.stats_out) {
+    const int which = threadIdx.x >> 6, c = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (c < p.Nout) {
+      const double* q = red + which * 256 + (threadIdx.x & 63);
+      unsafeAtomicAdd(p.stats_out + which * p.Nout + c, q[0] + q[64] + q[128] + q[192]);
+    }
+  }
+}
+
 // Generic path for shapes the MFMA kernel does not take (K not a multiple of 32, unaligned rows): the small
 // edge-side layers when MLP.forward is used as a stand-alone op.  One thread per output element.
 __global__ __launch_bounds__(256) void linear_generic_kernel(GemmParams p) {
@@ -189,30 +252,50 @@ __global__ __launch_bounds__(256) void linear_generic_kernel(GemmParams p) {
     for (int i = threadIdx.x; i < 2 * p.Nout; i += 256) unsafeAtomicAdd(p.stats_out + i, cs[i]);
 }
 
-template <int TM, int TN>
+template <int TM, int TN, int BK>
 static void launch_cfg(const GemmParams& p, hipStream_t s) {
-  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int BM = 64 * TM, BN = 64 * TN, LDK = BK + 4;
   const int tiles_m = (int)((p.M + BM - 1) / BM), tiles_n = (p.Nout + BN - 1) / BN;
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
-  size_t lds = (size_t)(BM + BN) * LDK * sizeof(float) + (size_t)2 * p.K * sizeof(float);
+  size_t lds = (size_t)(BM + BN) * LDK * sizeof(float) + (size_t)2 * (p.K / p.split_k) * sizeof(float);
   const size_t epi = (size_t)4 * BN * sizeof(double);
   if (lds < epi) lds = epi;
-  hipLaunchKernelGGL((gemm_bn_kernel<TM, TN>), dim3(grid), dim3(256), lds, s, p, tiles_m, tiles_n);
+  hipLaunchKernelGGL((gemm_bn_kernel<TM, TN, BK>), dim3(grid, p.split_k), dim3(256), lds, s, p, tiles_m, tiles_n);
+  if (p.split_k > 1)
+    hipLaunchKernelGGL(combine_stats_kernel, dim3((p.Nout + 63) / 64, (unsigned)((p.M + kCombRows - 1) / kCombRows)), dim3(256), 0, s, p);
+}
+
+// 0: MFMA kernel not applicable; 1: 64x64 tiles; 2: 128x128 tiles.  *split_k > 1 only for few-row problems,
+// where one block per output tile would leave most of the 256 CUs idle and serialise the whole K loop.
+int gemm_plan(int64_t M, int K, int Nout, int* split_k) {
+  constexpr int BK = 64;
+  *split_k = 1;
+  if (K % 32 != 0 || K > 6144) return 0;
+  const int64_t big_tiles = ((M + 127) / 128) * ((Nout + 127) / 128);
+  if (big_tiles >= 512 && Nout >= 128) return 2;
+  const int64_t tiles = ((M + 63) / 64) * ((Nout + 63) / 64);
+  int s = 1;
+  while (s < kMaxSplit && tiles * (s * 2) <= 1024 && K % (s * 2 * BK) == 0 && K / (s * 2) >= 64) s *= 2;
+  if (tiles < 256) *split_k = s;
+  return 1;
 }
 
 int launch_gemm_bn(const GemmParams& p, hipStream_t s) {
   if (p.M < 1 || p.Nout < 1 || p.K < 1) return MTMC_E_ARG;
-  if (p.K % BK != 0 || p.K > 6144 || (p.lda % 4) != 0 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) {
+  if (p.K % 32 != 0 || p.K > 6144 || (p.lda % 4) != 0 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) {
     if (p.stats_in != nullptr || p.Nout > 2048) return MTMC_E_ARG;
     const int64_t blocks = (p.M * p.Nout + 255) / 256;
     hipLaunchKernelGGL(linear_generic_kernel, dim3((int)(blocks > 2048 ? 2048 : blocks)), dim3(256),
                        (size_t)2 * p.Nout * sizeof(double), s, p);
     return MTMC_OK;
   }
-  // big problems: 128x128 tiles; small ones (few row panels): 64x64 tiles to put more blocks on the chip
-  const int64_t big_tiles = ((p.M + 127) / 128) * ((p.Nout + 127) / 128);
-  if (big_tiles >= 512 && p.Nout >= 128) launch_cfg<2, 2>(p, s);
-  else launch_cfg<1, 1>(p, s);
+  GemmParams q = p;
+  int sk;
+  const int cfg = gemm_plan(p.M, p.K, p.Nout, &sk);
+  q.split_k = (p.slab != nullptr) ? sk : 1;
+  if (cfg == 2) launch_cfg<2, 2, 32>(q, s);
+  else if ((p.K / q.split_k) % 64 == 0) launch_cfg<1, 1, 64>(q, s);
+  else launch_cfg<1, 1, 32>(q, s);
   return MTMC_OK;
 }
 

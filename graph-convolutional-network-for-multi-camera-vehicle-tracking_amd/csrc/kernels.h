@@ -31,6 +31,9 @@ struct RoundParams {
 };
 
 struct NodeProjParams {
+  // fused first round: h = relu(bn(y_last)) computed on the fly (and stored to h0_out) instead of read from h_src
+  const float* y_last; const double* y_stats; const float* y_gamma; const float* y_beta; double y_count; float* h0_out;
+  int finalize_enc; EdgeEncParams enc; double e_total;   // block 0 also finalises the edge-encoder affines
   const float* h_src;        // [N][32]
   const float* h0;           // [N][32] (reattach_nodes) or nullptr
   const int* deg;            // mean aggregation: scale h_src rows by 1/max(deg,1); else nullptr
@@ -59,6 +62,8 @@ struct GemmParams {
   double count;                      // BatchNorm row count (global N)
   double* stats_out;                 // f64[2*Nout], accumulated atomically
   int64_t M; int K; int Nout;
+  float* slab;                       // [split_k][M][Nout] scratch for split-K partial tiles, or nullptr
+  int split_k;                       // set by launch_gemm_bn
 };
 
 void launch_prep(const PrepParams& p, hipStream_t s);
@@ -79,6 +84,7 @@ void launch_bn_relu_rows(const float* Y, int64_t ldy, int64_t rows, int dim, con
 void launch_h_final(const float* src, const int* deg, int mean, int64_t n_nodes, float* dst, hipStream_t s);
 
 int launch_gemm_bn(const GemmParams& p, hipStream_t s);   // returns 0 or MTMC_E_ARG
+int gemm_plan(int64_t M, int K, int Nout, int* split_k);
 
 void launch_scatter(const float* src, const int64_t* index, int64_t n_src, int64_t n_cols, int64_t dim_size,
                     float* out, float* count, int64_t* arg_out, int mode, hipStream_t s);

@@ -17,6 +17,9 @@ constexpr int kProjOut = 40;     // 4 (Pr) + 4 (Pc) + 32 (Q)
 __global__ __launch_bounds__(256) void node_proj_kernel(NodeProjParams p) {
   __shared__ float wt[64 * kProjOut];              // [k][j], k < hn
   __shared__ float hs[kProjNodes * 65];            // [node][k], row stride hn+1
+  __shared__ float ys[kH], yt[kH];                 // BatchNorm affine of the encoder's last layer (fused round 0)
+  __shared__ EdgeEncAffine enc_af;
+  __shared__ double scratch[kStatAttr + kStatEnc2];
   const int hn = p.hn, ldh = hn + 1;
   for (int i = threadIdx.x; i < hn * kProjOut; i += blockDim.x) {
     const int kk = i / kProjOut, j = i % kProjOut;
@@ -26,25 +29,30 @@ __global__ __launch_bounds__(256) void node_proj_kernel(NodeProjParams p) {
     else w = p.un_w[(j - 8) * p.un_ld + kk];
     wt[i] = w;
   }
+  if (p.y_last && threadIdx.x < kH)
+    bn_affine(p.y_stats[threadIdx.x], p.y_stats[kH + threadIdx.x], p.y_count, p.y_gamma[threadIdx.x],
+              p.y_beta[threadIdx.x], ys[threadIdx.x], yt[threadIdx.x]);
   const int nl = threadIdx.x >> 3, part = threadIdx.x & 7;
   const int64_t n_groups = (p.n_nodes + kProjNodes - 1) / kProjNodes;
   for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
     const int64_t node0 = g * kProjNodes;
-    __syncthreads();                               // wt ready / previous hs consumed
-    // stage [h0 | h] rows of 32 nodes (1024 or 2048 floats)
-    for (int i = threadIdx.x; i < kProjNodes * hn; i += blockDim.x) {
-      const int n = i / hn, kk = i % hn;
+    __syncthreads();                               // wt/ys ready / previous hs consumed
+    // stage the h rows of 32 nodes (1024 floats), then mirror / fetch the h0 half when reattaching
+    for (int i = threadIdx.x; i < kProjNodes * kH; i += blockDim.x) {
+      const int n = i >> 5, kk = i & 31;
       const int64_t node = node0 + n;
       float v = 0.f;
       if (node < p.n_nodes) {
-        if (hn == 64 && kk < 32) {
-          v = p.h0[node * kH + kk];
+        if (p.y_last) {
+          v = fmaxf(fmaf(p.y_last[node * kH + kk], ys[kk], yt[kk]), 0.f);
+          p.h0_out[node * kH + kk] = v;
         } else {
-          v = p.h_src[node * kH + (kk & 31)];
+          v = p.h_src[node * kH + kk];
           if (p.deg) { const int d = p.deg[node]; v = v / (float)(d > 1 ? d : 1); }
         }
       }
-      hs[n * ldh + kk] = v;
+      hs[n * ldh + (hn - kH) + kk] = v;
+      if (hn == 2 * kH) hs[n * ldh + kk] = (p.y_last || node >= p.n_nodes) ? v : p.h0[node * kH + kk];
     }
     if (p.zero_buf) {                              // 32 nodes x 32 floats = 256 float4
       const int64_t node = node0 + (threadIdx.x >> 3);
@@ -64,6 +72,10 @@ __global__ __launch_bounds__(256) void node_proj_kernel(NodeProjParams p) {
 #pragma unroll
       for (int i = 1; i < 5; ++i) p.Q[node * kH + part + 8 * (i - 1)] = acc[i];
     }
+  }
+  if (p.finalize_enc && blockIdx.x == 0) {         // once per forward: the edge encoder's two BatchNorm affines
+    edge_enc_affine_to_smem(p.enc, p.e_total, 2, &enc_af, scratch);
+    if (threadIdx.x < 16) p.enc.aff[threadIdx.x] = reinterpret_cast<const float*>(&enc_af)[threadIdx.x];
   }
 }
 

@@ -103,6 +103,8 @@ typedef struct mtmc_mpn_call {
 } mtmc_mpn_call;
 
 #define MTMC_F_DETERMINISTIC 1   /* reserved: order-independent segment sums            */
+#define MTMC_F_FORK 2            /* run the edge branch (prep, edge-encoder moments) on an internal side stream
+                                    beside the node-encoder GEMMs, joined by events (default: one stream) */
 
 /* Byte offsets inside the workspace of the regions a multi-GPU host exchanges between phases. */
 typedef struct mtmc_ws_layout {
