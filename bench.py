@@ -233,7 +233,7 @@ def main():
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or os.environ.get("MTMC_BENCH_FORCE_DIST"):
         from bench_dist import main_distributed   # multi-GPU leg lives beside this file
         return main_distributed(args)
 
@@ -254,6 +254,8 @@ def main():
         st = run_single("cfg4", device, max(5, args.steps // 10), max(2, args.warmup // 10), with_cpu=not args.no_cpu,
                         phase_iters=5)
         line["stress"] = st
+        # the multi-GPU workload (config 5) on this one GPU: the N=1 point of the strong-scaling curve
+        line["scale_base"] = run_single("cfg5", device, 5, 2, with_cpu=False, phase_iters=2)
     print(json.dumps(line))
 
 

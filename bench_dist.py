@@ -1,0 +1,112 @@
+"""Multi-GPU leg of bench.py: the 1M-node / 100M-edge graph (BASELINE config 5) edge-range partitioned over
+the ranks of one node, one process per GPU, RCCL (torch.distributed backend "nccl") over xGMI.
+
+Launched by the driver as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+Strong scaling: the graph is fixed, each rank streams E/N edges and encodes N_nodes/N node rows; the replicated
+[N,32] node state is all-reduced after every round (mtmc_mpn/distributed.py).  value = total edges / step time,
+step time = max over ranks between two barriers.
+"""
+import copy
+import json
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+import mtmc_mpn
+from mtmc_mpn import _lib, distributed as mdist, graphs
+
+ARCH = "resnet101"
+
+
+def main_distributed(args):
+    import bench
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    device = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(device)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    name = "cfg5" if args.workload == "auto" else args.workload
+    desc, L, cs = bench.WORKLOADS[name]
+    params = mtmc_mpn.default_params(num_enc_steps=L, num_class_steps=cs)
+    torch.manual_seed(0)
+    model = mtmc_mpn.MOTMPNet(copy.deepcopy(params), None, ARCH).to(device).eval()
+
+    # every rank generates the same seeded graph on its own GPU, then keeps only its shard
+    full = bench.make_workload(name, device)
+    n, e = full.x.shape[0], full.edge_index.shape[1]
+    lo, hi = mdist.even_ranges(n, world)[rank]
+    elo, ehi = mdist.edge_ranges(full.edge_index[0], e, world, snap_to_rows=True)[rank]
+    x_loc = full.x[lo:hi].clone()
+    ei_loc = full.edge_index[:, elo:ehi].clone()
+    ea_loc = full.edge_attr[elo:ehi].clone()
+    del full
+    torch.cuda.empty_cache()
+
+    def step():
+        return mdist.sharded_forward(model, x_loc, (lo, hi, n), ei_loc, ea_loc, e)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        t1 = time.perf_counter()
+    t = torch.tensor([(t1 - t0) / args.steps], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    sec = float(t.item())
+
+    # per-phase split on this rank (kernels vs collectives), a few extra iterations with events
+    eng = model._engine
+    split = {"kernels_ms": 0.0, "collectives_ms": 0.0}
+    with torch.no_grad():
+        prep_evs = []
+
+        class Timed(mdist.ShardedForward):
+            def _sum(self, tns):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); super()._sum(tns); b.record(); prep_evs.append((a, b))
+
+            def _max(self, tns):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); super()._max(tns); b.record(); prep_evs.append((a, b))
+        timed = Timed(eng, model.spec)
+        reps = 3
+        s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_ev.record()
+        for _ in range(reps):
+            timed(x_loc, (lo, hi, n), ei_loc, ea_loc, e)
+        e_ev.record()
+        torch.cuda.synchronize(device)
+        coll = sum(a.elapsed_time(b) for a, b in prep_evs) / reps
+        total = s_ev.elapsed_time(e_ev) / reps
+        split = {"collectives_ms": coll, "kernels_and_gather_ms": total - coll, "step_ms_this_rank": total}
+
+    if rank == 0:
+        b_fwd = bench.algorithmic_bytes_forward(n, e, L, cs)
+        line = {"metric": "MPN forward edges/sec (+ achieved roofline fraction of the dominant kernel)",
+                "value": e / sec, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": sec * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic (seeded graph and features; random-init weights)",
+                "config": {"workload": f"{name}: {desc}, L={L}, Cs={cs}, eval forward", "N": n, "E": e,
+                           "parallelism": f"edge-range x{world} (rows of x range-partitioned for the encoder), "
+                                          "RCCL all-reduce of BatchNorm statistics and of the [N,32] node state per round"},
+                "roofline": None, "cpu_baseline": None,
+                "forward_algorithmic": {"bytes": b_fwd, "GBps": b_fwd / sec / 1e9,
+                                        "frac_of_aggregate_hbm_peak": b_fwd / sec / 1e9 / (bench.HBM_PEAK_GBS * world)},
+                "rank0_split": split}
+        print(json.dumps(line))
+    dist.destroy_process_group()

@@ -45,12 +45,13 @@ class WsLayout(C.Structure):
     _fields_ = [("total_bytes", C.c_size_t), ("zero_bytes", C.c_size_t), ("flags_off", C.c_size_t),
                 ("stat_attr_off", C.c_size_t), ("stat_enc2_off", C.c_size_t), ("stat_enc_node_off", C.c_size_t),
                 ("stat_round_off", C.c_size_t), ("deg_off", C.c_size_t), ("seg_off", C.c_size_t),
-                ("h0_off", C.c_size_t), ("h_acc_off", C.c_size_t * 2)]
+                ("h0_off", C.c_size_t), ("h_acc_off", C.c_size_t * 2), ("deg_global_off", C.c_size_t)]
 
 
-# doubles per statistics block (csrc/common.h)
-STAT_ATTR, STAT_ENC2, STAT_ROUND = 6, 16, 88
-ROUND_Z1, ROUND_M1, ROUND_Z2 = (0, 8), (8, 22), (22, 86)     # [begin, end) inside a round block
+# statistics blocks (include/mtmc_mpn.h): replicas x stride doubles each
+STAT_REPLICAS, ATTR_STRIDE, ENC2_STRIDE, Z1_STRIDE, M_STRIDE, Z2_STRIDE = 16, 16, 16, 16, 16, 64
+ROUND_BLOCK = STAT_REPLICAS * (Z1_STRIDE + M_STRIDE + Z2_STRIDE)
+F_GLOBAL_DEG, F_FORK = 4, 2
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmtmc_mpn.so")
 EXPORTS = ["mtmc_mpn_abi_version", "mtmc_mpn_last_error", "mtmc_mpn_workspace_bytes", "mtmc_mpn_workspace_layout",

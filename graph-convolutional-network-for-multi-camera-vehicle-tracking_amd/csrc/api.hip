@@ -72,10 +72,11 @@ void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* lo) {
     lo->stat_enc_layer[l] = lo->pub.stat_enc_node_off + acc * sizeof(double);
     acc += 2 * (size_t)m->enc_node[l].out_dim;
   }
-  lo->pub.stat_round_off = take((size_t)(L > 0 ? L : 1) * mtmc::kStatRep * mtmc::kRoundStride * sizeof(double));
+  lo->pub.stat_round_off = take((size_t)(L > 0 ? L : 1) * mtmc::kRoundBlock * sizeof(double));
   lo->pub.deg_off = take((size_t)N * sizeof(int32_t));
   lo->pub.seg_off = take((size_t)N * 4 * sizeof(double));
   lo->pub.zero_bytes = off;
+  lo->pub.deg_global_off = take((size_t)N * sizeof(int32_t));
   lo->pub.h0_off = take((size_t)N * 32 * sizeof(float));
   lo->pub.h_acc_off[0] = take((size_t)N * 32 * sizeof(float));
   lo->pub.h_acc_off[1] = take((size_t)N * 32 * sizeof(float));
@@ -163,7 +164,7 @@ mtmc::RoundParams round_params(const Ctx& x, int r) {
   p.un_w = m->upd_node.weight; p.un_b = m->upd_node.bias; p.un_g = m->upd_node.gamma; p.un_bt = m->upd_node.beta;
   p.un_ld = m->upd_node.in_dim; p.un_eoff = hn;
   p.cls_w = m->cls.weight; p.cls_b = m->cls.bias; p.n_classes = m->cls.out_dim;
-  p.stats = x.at<double>(x.lo.pub.stat_round_off) + (size_t)r * mtmc::kStatRep * mtmc::kRoundStride;
+  p.stats = x.at<double>(x.lo.pub.stat_round_off) + (size_t)r * mtmc::kRoundBlock;
   p.seg = x.at<double>(x.lo.pub.seg_off);
   p.h_acc = agg_target(x, r);
   const int step = r + 1;
@@ -177,6 +178,10 @@ mtmc::RoundParams round_params(const Ctx& x, int r) {
 }
 
 enum { kPhMemset = -1, kPhPrep = -2 };   // the two halves of MTMC_PH_BEGIN, for the forked forward
+
+const int* scale_deg(const Ctx& x) {   // the degree mean aggregation divides by
+  return x.at<int>((x.c->flags & MTMC_F_GLOBAL_DEG) ? x.lo.pub.deg_global_off : x.lo.pub.deg_off);
+}
 
 int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
   const mtmc_mpn_model* m = x.m;
@@ -249,7 +254,7 @@ int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
       p.finalize_enc = arg == 0; p.enc = enc_params(x); p.e_total = (double)c->n_edges_total;
       p.h_src = arg == 0 ? x.at<float>(x.lo.pub.h0_off) : x.at<float>(x.lo.pub.h_acc_off[(arg - 1) & 1]);
       p.h0 = m->reattach_nodes ? x.at<float>(x.lo.pub.h0_off) : nullptr;
-      p.deg = (m->agg == MTMC_AGG_MEAN && arg > 0) ? x.at<int>(x.lo.pub.deg_off) : nullptr;
+      p.deg = (m->agg == MTMC_AGG_MEAN && arg > 0) ? scale_deg(x) : nullptr;
       p.ue_w = m->upd_edge.weight; p.ue_ld = m->upd_edge.in_dim;
       p.un_w = m->upd_node.weight; p.un_ld = m->upd_node.in_dim;
       p.hn = (m->reattach_nodes ? 2 : 1) * MTMC_NODE_DIM;
@@ -276,7 +281,7 @@ int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
       p.Q = x.at<float>(x.lo.Q); p.deg = x.at<int>(x.lo.pub.deg_off); p.seg = x.at<double>(x.lo.pub.seg_off);
       p.un_w = m->upd_node.weight; p.un_b = m->upd_node.bias; p.un_ld = m->upd_node.in_dim;
       p.un_eoff = (m->reattach_nodes ? 2 : 1) * MTMC_NODE_DIM;
-      p.stats = x.at<double>(x.lo.pub.stat_round_off) + (size_t)arg * mtmc::kStatRep * mtmc::kRoundStride;
+      p.stats = x.at<double>(x.lo.pub.stat_round_off) + (size_t)arg * mtmc::kRoundBlock;
       p.n_nodes = c->n_nodes;
       mtmc::launch_node_stat(p, s);
       break;
@@ -284,7 +289,7 @@ int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
     case MTMC_PH_END: {
       const float* src = L == 0 ? x.at<float>(x.lo.pub.h0_off) : x.at<float>(x.lo.pub.h_acc_off[(L - 1) & 1]);
       if (L == 0 || m->agg == MTMC_AGG_MEAN)     // otherwise the last round already aggregated into h_out
-        mtmc::launch_h_final(src, x.at<int>(x.lo.pub.deg_off), (m->agg == MTMC_AGG_MEAN && L > 0) ? 1 : 0, c->n_nodes, c->h_out, s);
+        mtmc::launch_h_final(src, scale_deg(x), (m->agg == MTMC_AGG_MEAN && L > 0) ? 1 : 0, c->n_nodes, c->h_out, s);
       if (L == 0 && c->n_edges > 0)
         mtmc::launch_classify_e0(enc_params(x), c->edge_attr, c->n_edges, (double)c->n_edges_total, m->cls.weight,
                                  m->cls.bias, m->cls.out_dim, c->logits, s);

@@ -20,15 +20,18 @@ constexpr int kHe = 4;    // edge state width
 // round stats  : z1 sum[4] | z1 sumsq[4] | e' m1[4] | e' m2 packed[10] | z2 sum[32] | z2 sumsq[32]
 constexpr int kStatAttr = 6;
 constexpr int kStatEnc2 = 16;
-constexpr int kRoundZ1 = 0, kRoundM1 = 8, kRoundM2 = 12, kRoundZ2 = 22, kRoundStats = 86;
+// a round's statistics are three separately replicated blocks (each contiguous, so a multi-GPU host can
+// all-reduce them one at a time): z1 sum[4]|sumsq[4]  ;  e' m1[4]|m2 packed[10]  ;  z2 sum[32]|sumsq[32]
 // Every such block is kept in kStatRep replicas (each padded to a 128-byte multiple): a workgroup adds its
 // partial sums to replica blockIdx % kStatRep, the consumer adds the replicas up.  Hundreds of workgroups
 // adding to ONE cache line serialise at the memory side (float atomics run an order of magnitude slower
 // on a single row, MI355X_MICROARCH 'Global float atomics'); 16 lines remove that.
 constexpr int kStatRep = 16;
 __host__ __device__ __forceinline__ constexpr int stat_stride(int n) { return (n + 15) / 16 * 16; }
-constexpr int kAttrStride = stat_stride(kStatAttr), kEnc2Stride = stat_stride(kStatEnc2),
-              kRoundStride = stat_stride(kRoundStats);   // doubles per replica
+constexpr int kAttrStride = stat_stride(kStatAttr), kEnc2Stride = stat_stride(kStatEnc2);   // doubles per replica
+constexpr int kZ1Stride = 16, kMStride = 16, kZ2Stride = 64;
+constexpr int kRoundZ1Off = 0, kRoundMOff = kStatRep * kZ1Stride, kRoundZ2Off = kRoundMOff + kStatRep * kMStride;
+constexpr int kRoundBlock = kRoundZ2Off + kStatRep * kZ2Stride;   // doubles per round
 
 __host__ __device__ __forceinline__ constexpr int tri(int n, int i, int j) { return i * n - i * (i - 1) / 2 + (j - i); }
 

@@ -169,14 +169,14 @@ __global__ __launch_bounds__(256) void pass_a_kernel(RoundParams p) {
         acc[4 + k] += (double)z[i][k] * z[i][k];
       }
   }
-  block_atomic_add<8>(acc, p.stats + kRoundZ1, kRoundStride, red);
+  block_atomic_add<8>(acc, p.stats + kRoundZ1Off, kZ1Stride, red);
 }
 
 __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
   __shared__ EdgeEncAffine af;
   __shared__ float s1[4], t1[4];
   __shared__ double red[14 * 4];
-  stat_gather(p.stats + kRoundZ1, 8, kRoundStride, red);
+  stat_gather(p.stats + kRoundZ1Off, 8, kZ1Stride, red);
   if (p.first_round || p.reattach_edges) edge_enc_affine_load(p.enc, &af); else __syncthreads();
   if (threadIdx.x < 4) {
     const int k = threadIdx.x;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
       }
     }
   }
-  block_atomic_add<14>(acc, p.stats + kRoundM1, kRoundStride, red);
+  block_atomic_add<14>(acc, p.stats + kRoundMOff, kMStride, red);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -265,17 +265,18 @@ __device__ __forceinline__ void flush_node(const RoundParams& p, int node, int k
 __global__ __launch_bounds__(256) void pass_c_kernel(RoundParams p) {
   __shared__ float4 tile_e[kTileC];
   __shared__ int tile_row[kTileC];
-  __shared__ double st[kRoundStats - kRoundM2];   // e' second moments (10) | z2 sums (32) | z2 sums of squares (32)
+  __shared__ double st[10 + 64];           // e' second moments (10) | z2 sums (32) | z2 sums of squares (32)
   const int k = threadIdx.x & 31;          // channel
   const int hw = threadIdx.x >> 5;         // half-wave 0..7
   // BatchNorm affine of channel k of z2 from the moment statistics (node_stat_kernel + pass B)
-  stat_gather(p.stats + kRoundM2, kRoundStats - kRoundM2, kRoundStride, st);
+  stat_gather(p.stats + kRoundMOff + 4, 10, kMStride, st);
+  stat_gather(p.stats + kRoundZ2Off, 64, kZ2Stride, st + 10);
   __syncthreads();
   float sk, tk;
   {
     const float* a = p.un_w + k * p.un_ld + p.un_eoff;
     const double quad = quad_form(a, 4, st);
-    bn_affine(st[kRoundZ2 - kRoundM2 + k], st[kRoundZ2 - kRoundM2 + 32 + k] + quad, p.e_total, p.un_g[k], p.un_bt[k], sk, tk);
+    bn_affine(st[10 + k], st[10 + 32 + k] + quad, p.e_total, p.un_g[k], p.un_bt[k], sk, tk);
   }
   float a4[4];
 #pragma unroll

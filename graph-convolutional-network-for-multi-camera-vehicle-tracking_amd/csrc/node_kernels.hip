@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void node_stat_kernel(NodeStatParams p) {
     const int kk = threadIdx.x & 31, which = threadIdx.x >> 5;
     double s = 0;
     for (int sl = 0; sl < 8; ++sl) s += red[which * 256 + sl * 32 + kk];
-    unsafeAtomicAdd(p.stats + (blockIdx.x % kStatRep) * kRoundStride + kRoundZ2 + which * 32 + kk, s);
+    unsafeAtomicAdd(p.stats + kRoundZ2Off + (blockIdx.x % kStatRep) * kZ2Stride + which * 32 + kk, s);
   }
 }
 

@@ -1,0 +1,134 @@
+"""Edge-range partitioned MPN forward over the GPUs of one node (not in the reference, which
+is single-GPU).  One process per GPU; `torch.distributed` (backend "nccl" = RCCL over xGMI) moves the data.
+
+Partitioning.  Rank r holds a contiguous slice of the edge list (`edge_index`, `edge_attr`, and therefore the
+edge states and logits, which never leave the rank) and a contiguous slice of the node rows of `x` (the 8 KB/node
+features stay local for the encoder GEMMs).  The 32-wide node state is replicated.
+
+Exchanges per forward -- BatchNorm couples every row, so each statistics block is all-reduced (fp64, a few
+hundred bytes to a few KB each), plus the two real data exchanges:
+    after BEGIN      edge_attr moments                     (+ the degree, for mean aggregation only)
+    after EDGE_ENC   hidden edge-encoder moments
+    after NODE_ENC l column statistics of layer l
+    after NODE_H0    all-gather of the encoded node rows h0                       [N,32] f32
+    per round        z1 statistics | e' moments | z2 statistics (three small all-reduces)
+                     all-reduce (sum or max) of the aggregated node state h'      [N,32] f32
+The per-node segment sums and degrees need no exchange: the z2 statistics are linear in them, so every rank
+evaluates its share and only the 64 sums travel.
+
+The phase sequence itself is the single-GPU one (ForwardEngine.phase_list / mtmc_mpn_run_phase); this file only
+decides what is exchanged after which phase.  It talks to the kernels through the small backend interface
+(prepare / phase_list / run_phase / region / outputs), which is what lets tests/ drive the same code with a CPU
+stand-in over gloo.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+def even_ranges(total: int, parts: int) -> List[Tuple[int, int]]:
+    """Contiguous [lo, hi) ranges, the first `total % parts` one element longer."""
+    base, extra = divmod(total, parts)
+    out, lo = [], 0
+    for r in range(parts):
+        hi = lo + base + (1 if r < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def edge_ranges(row: Optional[torch.Tensor], n_edges: int, parts: int, snap_to_rows: bool = False):
+    """Edge ranges per rank; with `snap_to_rows` (row-sorted lists) boundaries move to the next row change so
+    that every node's out-edges live on one rank."""
+    ranges = even_ranges(n_edges, parts)
+    if not snap_to_rows or row is None or n_edges == 0:
+        return ranges
+    cuts = [0]
+    for lo, hi in ranges[:-1]:
+        c = max(hi, cuts[-1])
+        if 0 < c < n_edges:
+            same = (row[c:] != row[c - 1]).nonzero()
+            c = n_edges if same.numel() == 0 else c + int(same[0])
+        cuts.append(min(c, n_edges))
+    cuts.append(n_edges)
+    return [(cuts[i], cuts[i + 1]) for i in range(parts)]
+
+
+class ShardedForward:
+    """Runs one forward on this rank's shard.  `backend` is a ForwardEngine (HIP) or anything with the same
+    five methods."""
+
+    def __init__(self, backend, spec, group=None):
+        self.backend, self.spec, self.group = backend, spec, group
+
+    # collectives (in place on workspace views)
+    def _sum(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _max(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+
+    def __call__(self, x_local, node_range, edge_index_local, edge_attr_local, n_edges_total):
+        """x_local: rows [node_range[0], node_range[1]) of x; node_range = (lo, hi, N).
+        edge_index_local / edge_attr_local: this rank's edge slice (global node ids)."""
+        be, spec = self.backend, self.spec
+        world = dist.get_world_size(self.group)
+        rank = dist.get_rank(self.group)
+        prep = be.prepare(x_local, edge_index_local, edge_attr_local, n_edges_total=n_edges_total,
+                          node_range=node_range)
+        n = node_range[2]
+        mean = spec.agg == "mean"
+        if mean:
+            be.set_flags(prep, _lib.F_GLOBAL_DEG)
+        rows = even_ranges(n, world)
+        if tuple(rows[rank]) != tuple(node_range[:2]):
+            raise ValueError(f"rank {rank} must encode node rows {rows[rank]} (even_ranges), got {node_range[:2]}")
+
+        for ph, arg in be.phase_list():
+            be.run_phase(prep, ph, arg)
+            if ph == _lib.PH_BEGIN:
+                self._sum(be.region(prep, "stat_attr"))
+                if mean:
+                    g = be.region(prep, "deg_global")
+                    g.copy_(be.region(prep, "deg"))
+                    self._sum(g)
+            elif ph == _lib.PH_EDGE_ENC:
+                self._sum(be.region(prep, "stat_enc2"))
+            elif ph == _lib.PH_NODE_ENC:
+                self._sum(be.region(prep, "stat_enc_node", arg))
+            elif ph == _lib.PH_NODE_H0:
+                h0 = be.region(prep, "h0")
+                even = all(hi - lo == rows[0][1] - rows[0][0] for lo, hi in rows)
+                if even and dist.get_backend(self.group) == "nccl":
+                    dist.all_gather_into_tensor(h0, h0[rows[rank][0]:rows[rank][1]].clone(), group=self.group)
+                else:                              # uneven split: one broadcast per owner
+                    for r, (lo, hi) in enumerate(rows):
+                        if hi > lo:
+                            dist.broadcast(h0[lo:hi], src=dist.get_global_rank(self.group, r) if self.group else r,
+                                           group=self.group)
+            elif ph == _lib.PH_ROUND_A:
+                self._sum(be.region(prep, "round_z1", arg))
+            elif ph == _lib.PH_ROUND_B:
+                self._sum(be.region(prep, "round_m", arg))
+            elif ph == _lib.PH_ROUND_STAT:
+                self._sum(be.region(prep, "round_z2", arg))
+            elif ph == _lib.PH_ROUND_C:
+                h = be.region(prep, "agg", arg)
+                (self._max if spec.agg == "max" else self._sum)(h)
+        return be.outputs(prep)
+
+
+def sharded_forward(module, x_local, node_range, edge_index_local, edge_attr_local, n_edges_total, group=None):
+    """Convenience wrapper: one edge-partitioned forward of a (HIP-backed) MOTMPNet on this rank's shard.
+    Returns ({'classified_edges': [local logits]}, h) with h replicated on every rank."""
+    from . import engine
+    if module._engine is None:
+        module._engine = engine.ForwardEngine(module)
+    logits, h = ShardedForward(module._engine, module.spec, group)(x_local, node_range, edge_index_local,
+                                                                  edge_attr_local, n_edges_total)
+    return {"classified_edges": logits}, h

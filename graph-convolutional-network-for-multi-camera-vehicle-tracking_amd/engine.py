@@ -146,6 +146,55 @@ class ForwardEngine:
                     (_lib.PH_ROUND_C, r)]
         return seq + [(_lib.PH_END, 0)]
 
+    # -- phase backend interface used by mtmc_mpn.distributed ------------------------------------------
+    def run_phase(self, prep, ph, arg):
+        with torch.cuda.device(prep.dev):
+            _lib.check(self.lib.mtmc_mpn_run_phase(C.byref(prep.model), C.byref(prep.call), ph, arg))
+
+    def set_flags(self, prep, flags):
+        prep.call.flags = int(flags)
+
+    def region(self, prep, name, idx=0) -> torch.Tensor:
+        """A tensor aliasing one exchanged region of the workspace (include/mtmc_mpn.h, mtmc_ws_layout)."""
+        lay = getattr(prep, "_layout", None)
+        if lay is None:
+            lay = prep._layout = self.layout(prep)
+        ws, n, s = prep.ws, prep.n, self.spec
+        R = _lib.STAT_REPLICAS
+
+        def f64(off, count):
+            return ws[off:off + 8 * count].view(torch.float64)
+
+        if name == "stat_attr":
+            return f64(lay.stat_attr_off, R * _lib.ATTR_STRIDE)
+        if name == "stat_enc2":
+            return f64(lay.stat_enc2_off, R * _lib.ENC2_STRIDE)
+        if name == "stat_enc_node":
+            off = lay.stat_enc_node_off + 8 * sum(2 * l.out_dim for l in s.enc_node[:idx])
+            return f64(off, 2 * s.enc_node[idx].out_dim)
+        if name in ("round_z1", "round_m", "round_z2"):
+            base = lay.stat_round_off + 8 * idx * _lib.ROUND_BLOCK
+            if name == "round_z1":
+                return f64(base, R * _lib.Z1_STRIDE)
+            if name == "round_m":
+                return f64(base + 8 * R * _lib.Z1_STRIDE, R * _lib.M_STRIDE)
+            return f64(base + 8 * R * (_lib.Z1_STRIDE + _lib.M_STRIDE), R * _lib.Z2_STRIDE)
+        if name == "deg":
+            return ws[lay.deg_off:lay.deg_off + 4 * n].view(torch.int32)
+        if name == "deg_global":
+            return ws[lay.deg_global_off:lay.deg_global_off + 4 * n].view(torch.int32)
+        if name == "h0":
+            return ws[lay.h0_off:lay.h0_off + 128 * n].view(torch.float32).view(n, 32)
+        if name == "agg":                      # where round idx aggregates (see mtmc_ws_layout.h_acc_off)
+            if idx == s.num_enc_steps - 1 and s.agg != "mean":
+                return prep.h
+            off = lay.h_acc_off[idx & 1]
+            return ws[off:off + 128 * n].view(torch.float32).view(n, 32)
+        raise KeyError(name)
+
+    def outputs(self, prep):
+        return [prep.logits[i] for i in range(prep.n_out)], prep.h
+
     def layout(self, prep) -> _lib.WsLayout:
         lay = _lib.WsLayout()
         _lib.check(self.lib.mtmc_mpn_workspace_layout(C.byref(prep.model), prep.n, prep.e, C.byref(lay)))

@@ -103,22 +103,35 @@ typedef struct mtmc_mpn_call {
 } mtmc_mpn_call;
 
 #define MTMC_F_DETERMINISTIC 1   /* reserved: order-independent segment sums            */
+#define MTMC_F_GLOBAL_DEG 4      /* mean aggregation divides by workspace deg_global (multi-GPU) instead of deg */
 #define MTMC_F_FORK 2            /* run the edge branch (prep, edge-encoder moments) on an internal side stream
                                     beside the node-encoder GEMMs, joined by events (default: one stream) */
 
-/* Byte offsets inside the workspace of the regions a multi-GPU host exchanges between phases. */
+/* Byte offsets inside the workspace of the regions a multi-GPU host exchanges between phases.
+ * Every statistics block is kept in MTMC_STAT_REPLICAS replicas (consumers add them up), so a host simply
+ * all-reduces the whole replicated block.  Strides are in doubles. */
+#define MTMC_STAT_REPLICAS 16
+#define MTMC_ATTR_STRIDE 16      /* edge_attr moments : m1[2] | m2 packed upper triangle[3]                */
+#define MTMC_ENC2_STRIDE 16      /* hidden edge-encoder moments : m1[4] | m2 packed[10]                     */
+#define MTMC_Z1_STRIDE 16        /* edge-update pre-activation : sum[4] | sumsq[4]                          */
+#define MTMC_M_STRIDE 16         /* updated edge state e' : m1[4] | m2 packed[10]                           */
+#define MTMC_Z2_STRIDE 64        /* node-update pre-activation : sum[32] | sumsq[32] (without the A M A^T term) */
+#define MTMC_ROUND_BLOCK (MTMC_STAT_REPLICAS * (MTMC_Z1_STRIDE + MTMC_M_STRIDE + MTMC_Z2_STRIDE))
 typedef struct mtmc_ws_layout {
   size_t total_bytes;
-  size_t zero_bytes;         /* the leading region [0, zero_bytes) is cleared by MTMC_PH_BEGIN   */
-  size_t flags_off;          /* int32[8]: [0] rows out of order, [1] indices out of range        */
-  size_t stat_attr_off;      /* f64[2+4]      edge_attr first/second moments                     */
-  size_t stat_enc2_off;      /* f64[4+16]     moments of the edge-encoder hidden layer           */
-  size_t stat_enc_node_off;  /* f64[2*sum(out dims)] node-encoder column sums / sums of squares  */
-  size_t stat_round_off;     /* f64[L][8+20+64] per round: z1 stats, e' moments, z2 stats        */
-  size_t deg_off;            /* i32[N]        out-degree (row histogram)                         */
-  size_t seg_off;            /* f64[N][4]     per-node segment sums of e'                        */
-  size_t h0_off;             /* f32[N][32]    encoded node state                                 */
-  size_t h_acc_off[2];       /* f32[N][32] x2 aggregation ping-pong                              */
+  size_t zero_bytes;         /* the leading region [0, zero_bytes) is cleared by MTMC_PH_BEGIN           */
+  size_t flags_off;          /* int32[8]: [0] rows out of order, [1] indices out of range                */
+  size_t stat_attr_off;      /* f64[REPLICAS][ATTR_STRIDE]                                               */
+  size_t stat_enc2_off;      /* f64[REPLICAS][ENC2_STRIDE]                                               */
+  size_t stat_enc_node_off;  /* per encoder layer l, consecutively: f64[2][out_dim_l] column sum | sumsq  */
+  size_t stat_round_off;     /* f64[L][ROUND_BLOCK]: per round the z1, e'-moment and z2 blocks in order   */
+  size_t deg_off;            /* i32[N]  out-degree of the LOCAL edges (row histogram)                     */
+  size_t seg_off;            /* f64[N][4] per-node segment sums of e' over the LOCAL edges                */
+  size_t h0_off;             /* f32[N][32] encoded node state (rows node_lo..node_hi written locally)      */
+  size_t h_acc_off[2];       /* f32[N][32] x2 aggregation ping-pong: round r aggregates into [r & 1],
+                                except that the last round of a sum/max model aggregates into h_out       */
+  size_t deg_global_off;     /* i32[N]  degree over all shards; read instead of deg for mean aggregation
+                                when MTMC_F_GLOBAL_DEG is set (the host fills it)                         */
 } mtmc_ws_layout;
 
 enum {                       /* phases in forward order; `arg` = encoder layer or round (0-based) */
