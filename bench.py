@@ -31,6 +31,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # fp32-input MFMA dense peak
 
 PHASE_NAMES = {_lib.PH_BEGIN: "memset+prep_kernel", _lib.PH_EDGE_ENC: "enc2_kernel", _lib.PH_NODE_ENC: "gemm_bn_kernel",
+               _lib.PH_NODE_COMBINE: "combine_stats_kernel",
                _lib.PH_NODE_H0: "bn_relu_rows_kernel", _lib.PH_ROUND_PROJ: "node_proj_kernel",
                _lib.PH_ROUND_A: "pass_a_kernel", _lib.PH_ROUND_B: "pass_b_kernel", _lib.PH_ROUND_STAT: "node_stat_kernel",
                _lib.PH_ROUND_C: "pass_c_kernel", _lib.PH_END: "h_final_kernel"}
@@ -77,6 +78,7 @@ def phase_cost(ph, arg, spec, n, e):
     first = arg == 0
     e_in = 8 if (first and not spec.reattach_edges) else (24 if spec.reattach_edges and not first else 16 if not first else 8)
     table = {
+        _lib.PH_NODE_COMBINE: 0.0,
         _lib.PH_BEGIN: 16 * e + 8 * e + 8 * e + 4 * n,                 # int64 row/col + attr in, int32 row/col out, degree
         _lib.PH_EDGE_ENC: 8 * e,
         _lib.PH_NODE_H0: 256 * n,
@@ -184,11 +186,13 @@ def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
     sec = time_forward(model, data, steps, warmup)
     seq, ms = time_phases(model, data, phase_iters)
     spec = model.spec
-    # dominant kernel = the phase kind with the largest summed time
+    # dominant kernel = the kernel NAME with the largest summed time (all its launches in a step, the same
+    # granularity as a rocprofv3 --stats row); phases that launched nothing (un-split combine) are skipped
     by_kind = {}
     for (ph, arg), t in zip(seq, ms):
-        key = (ph, arg) if ph == _lib.PH_NODE_ENC else (ph, -1)
-        by_kind.setdefault(key, []).append(((ph, arg), t))
+        if ph == _lib.PH_NODE_COMBINE and t < 2e-3:
+            continue
+        by_kind.setdefault(ph, []).append(((ph, arg), t))
     dom_key = max(by_kind, key=lambda k: sum(t for _, t in by_kind[k]))
     launches = by_kind[dom_key]
     avg_ms = sum(t for _, t in launches) / len(launches)
@@ -199,7 +203,7 @@ def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
         achieved, peak, unit = work / (avg_ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
     else:
         achieved, peak, unit = work / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
-    kname = PHASE_NAMES[dom_key[0]] + (f"[layer {dom_key[1]}]" if dom_key[0] == _lib.PH_NODE_ENC else "")
+    kname = PHASE_NAMES[dom_key] + (" (all encoder layers)" if dom_key == _lib.PH_NODE_ENC else "")
     roofline = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
                 "traffic": None, "kernel": kname, "avg_kernel_ms": avg_ms, "launches_per_step": len(launches),
                 "algorithmic_per_launch": work}

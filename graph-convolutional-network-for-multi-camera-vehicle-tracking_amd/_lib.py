@@ -13,7 +13,7 @@ NODE_DIM, EDGE_DIM, MAX_CLASSES = 32, 4, 4
 AGG = {"sum": 0, "mean": 1, "max": 2}
 
 (PH_BEGIN, PH_EDGE_ENC, PH_NODE_ENC, PH_NODE_H0, PH_ROUND_PROJ, PH_ROUND_A, PH_ROUND_B, PH_ROUND_STAT,
- PH_ROUND_C, PH_END) = range(10)
+ PH_ROUND_C, PH_END, PH_NODE_COMBINE) = range(11)
 
 E_ARG, E_WORKSPACE, E_HIP, E_ROWS = -1, -2, -3, -4
 

@@ -208,7 +208,8 @@ int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
       if (c->n_edges > 0)
         mtmc::launch_enc2(enc_params(x), c->edge_attr, c->n_edges, (double)c->n_edges_total, x.at<double>(x.lo.pub.stat_enc2_off), s);
       break;
-    case MTMC_PH_NODE_ENC: {
+    case MTMC_PH_NODE_ENC:
+    case MTMC_PH_NODE_COMBINE: {
       if (arg < 0 || arg >= m->n_enc_layers) return fail(MTMC_E_ARG, "encoder layer %d out of range", arg);
       const int64_t rows = c->node_hi - c->node_lo;
       if (rows == 0) break;
@@ -232,7 +233,8 @@ int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
                      ? x.at<float>(x.lo.slab) : nullptr;
         g.split_k = 1;
       }
-      if (mtmc::launch_gemm_bn(g, s) != MTMC_OK) return fail(MTMC_E_ARG, "encoder layer %d: unsupported GEMM shape", arg);
+      if (mtmc::launch_gemm_bn(g, s, phase == MTMC_PH_NODE_ENC ? 1 : 2) != MTMC_OK)
+        return fail(MTMC_E_ARG, "encoder layer %d: unsupported GEMM shape", arg);
       break;
     }
     case MTMC_PH_NODE_H0: {
@@ -372,8 +374,10 @@ int32_t mtmc_mpn_forward(const mtmc_mpn_model* model, const mtmc_mpn_call* call)
     if ((rc = run_phase(x, MTMC_PH_BEGIN, 0))) return rc;
     if ((rc = run_phase(x, MTMC_PH_EDGE_ENC, 0))) return rc;
   }
-  for (int l = 0; l < model->n_enc_layers; ++l)
+  for (int l = 0; l < model->n_enc_layers; ++l) {
     if ((rc = run_phase(x, MTMC_PH_NODE_ENC, l))) return rc;
+    if ((rc = run_phase(x, MTMC_PH_NODE_COMBINE, l))) return rc;
+  }
   if (sd && hipStreamWaitEvent(x.stream, sd->join, 0) != hipSuccess) return fail(MTMC_E_HIP, "join failed");
   // single shard: h0 = relu(bn(Y_last)) is produced inside the first round's projection kernel
   const bool fused_h0 = model->num_enc_steps > 0 && call->node_lo == 0 && call->node_hi == call->n_nodes;

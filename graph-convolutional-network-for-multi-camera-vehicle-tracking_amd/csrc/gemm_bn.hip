@@ -261,8 +261,11 @@ static void launch_cfg(const GemmParams& p, hipStream_t s) {
   const size_t epi = (size_t)4 * BN * sizeof(double);
   if (lds < epi) lds = epi;
   hipLaunchKernelGGL((gemm_bn_kernel<TM, TN, BK>), dim3(grid, p.split_k), dim3(256), lds, s, p, tiles_m, tiles_n);
-  if (p.split_k > 1)
-    hipLaunchKernelGGL(combine_stats_kernel, dim3((p.Nout + 63) / 64, (unsigned)((p.M + kCombRows - 1) / kCombRows)), dim3(256), 0, s, p);
+}
+
+void launch_combine(const GemmParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(combine_stats_kernel, dim3((p.Nout + 63) / 64, (unsigned)((p.M + kCombRows - 1) / kCombRows)),
+                     dim3(256), 0, s, p);
 }
 
 // 0: MFMA kernel not applicable; 1: 64x64 tiles; 2: 128x128 tiles.  *split_k > 1 only for few-row problems,
@@ -280,10 +283,12 @@ int gemm_plan(int64_t M, int K, int Nout, int* split_k) {
   return 1;
 }
 
-int launch_gemm_bn(const GemmParams& p, hipStream_t s) {
+// which: 1 = the GEMM only, 2 = the split-K combine only (no-op for un-split layers), 3 = both
+int launch_gemm_bn(const GemmParams& p, hipStream_t s, int which) {
   if (p.M < 1 || p.Nout < 1 || p.K < 1) return MTMC_E_ARG;
   if (p.K % 32 != 0 || p.K > 6144 || (p.lda % 4) != 0 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) {
     if (p.stats_in != nullptr || p.Nout > 2048) return MTMC_E_ARG;
+    if (!(which & 1)) return MTMC_OK;
     const int64_t blocks = (p.M * p.Nout + 255) / 256;
     hipLaunchKernelGGL(linear_generic_kernel, dim3((int)(blocks > 2048 ? 2048 : blocks)), dim3(256),
                        (size_t)2 * p.Nout * sizeof(double), s, p);
@@ -293,9 +298,12 @@ int launch_gemm_bn(const GemmParams& p, hipStream_t s) {
   int sk;
   const int cfg = gemm_plan(p.M, p.K, p.Nout, &sk);
   q.split_k = (p.slab != nullptr) ? sk : 1;
-  if (cfg == 2) launch_cfg<2, 2, 32>(q, s);
-  else if ((p.K / q.split_k) % 64 == 0) launch_cfg<1, 1, 64>(q, s);
-  else launch_cfg<1, 1, 32>(q, s);
+  if (which & 1) {
+    if (cfg == 2) launch_cfg<2, 2, 32>(q, s);
+    else if ((p.K / q.split_k) % 64 == 0) launch_cfg<1, 1, 64>(q, s);
+    else launch_cfg<1, 1, 32>(q, s);
+  }
+  if ((which & 2) && q.split_k > 1) launch_combine(q, s);
   return MTMC_OK;
 }
 

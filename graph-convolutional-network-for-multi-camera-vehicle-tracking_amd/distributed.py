@@ -9,7 +9,7 @@ Exchanges per forward -- BatchNorm couples every row, so each statistics block i
 hundred bytes to a few KB each), plus the two real data exchanges:
     after BEGIN      edge_attr moments                     (+ the degree, for mean aggregation only)
     after EDGE_ENC   hidden edge-encoder moments
-    after NODE_ENC l column statistics of layer l
+    after NODE_COMBINE l  column statistics of encoder layer l
     after NODE_H0    all-gather of the encoded node rows h0                       [N,32] f32
     per round        z1 statistics | e' moments | z2 statistics (three small all-reduces)
                      all-reduce (sum or max) of the aggregated node state h'      [N,32] f32
@@ -99,7 +99,7 @@ class ShardedForward:
                     self._sum(g)
             elif ph == _lib.PH_EDGE_ENC:
                 self._sum(be.region(prep, "stat_enc2"))
-            elif ph == _lib.PH_NODE_ENC:
+            elif ph == _lib.PH_NODE_COMBINE:           # the layer's column statistics are complete here
                 self._sum(be.region(prep, "stat_enc_node", arg))
             elif ph == _lib.PH_NODE_H0:
                 h0 = be.region(prep, "h0")

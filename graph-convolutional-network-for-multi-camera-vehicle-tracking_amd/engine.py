@@ -139,7 +139,8 @@ class ForwardEngine:
         """(phase, arg) pairs of one forward, in order (what mtmc_mpn_forward runs internally)."""
         s = self.spec
         seq = [(_lib.PH_BEGIN, 0), (_lib.PH_EDGE_ENC, 0)]
-        seq += [(_lib.PH_NODE_ENC, l) for l in range(len(s.enc_node))]
+        for l in range(len(s.enc_node)):
+            seq += [(_lib.PH_NODE_ENC, l), (_lib.PH_NODE_COMBINE, l)]
         seq += [(_lib.PH_NODE_H0, 0)]
         for r in range(s.num_enc_steps):
             seq += [(_lib.PH_ROUND_PROJ, r), (_lib.PH_ROUND_A, r), (_lib.PH_ROUND_B, r), (_lib.PH_ROUND_STAT, r),

@@ -137,14 +137,16 @@ typedef struct mtmc_ws_layout {
 enum {                       /* phases in forward order; `arg` = encoder layer or round (0-based) */
   MTMC_PH_BEGIN = 0,         /* clear statistics; int64 -> int32 indices; degree; attr moments   */
   MTMC_PH_EDGE_ENC = 1,      /* moments of the edge-encoder hidden layer                         */
-  MTMC_PH_NODE_ENC = 2,      /* arg = layer: GEMM + column statistics                            */
+  MTMC_PH_NODE_ENC = 2,      /* arg = layer: GEMM (+ column statistics unless split along K)      */
   MTMC_PH_NODE_H0 = 3,       /* h0 = relu(bn(Y_last)) for rows [node_lo,node_hi)                 */
   MTMC_PH_ROUND_PROJ = 4,    /* arg = round: per-node projections Pr|Pc|Q, clear next h buffer   */
   MTMC_PH_ROUND_A = 5,       /* statistics of the edge-update pre-activation                     */
   MTMC_PH_ROUND_B = 6,       /* e' (stored), its moments and per-node segment sums               */
   MTMC_PH_ROUND_STAT = 7,    /* statistics of the node-update pre-activation by moments          */
   MTMC_PH_ROUND_C = 8,       /* messages, aggregation into h, classifier logits                  */
-  MTMC_PH_END = 9            /* mean scaling / copy of the final node state to h_out             */
+  MTMC_PH_END = 9,           /* mean scaling / copy of the final node state to h_out             */
+  MTMC_PH_NODE_COMBINE = 10  /* arg = layer, right after MTMC_PH_NODE_ENC: sums the split-K slabs of a few-row
+                                layer and takes its column statistics (no-op when the layer was not split) */
 };
 
 int32_t mtmc_mpn_abi_version(void);

@@ -55,7 +55,8 @@ class CpuPhaseBackend:
     def phase_list(self):
         s = self.spec
         seq = [(_lib.PH_BEGIN, 0), (_lib.PH_EDGE_ENC, 0)]
-        seq += [(_lib.PH_NODE_ENC, l) for l in range(len(s.enc_node))]
+        for l in range(len(s.enc_node)):
+            seq += [(_lib.PH_NODE_ENC, l), (_lib.PH_NODE_COMBINE, l)]
         seq += [(_lib.PH_NODE_H0, 0)]
         for r in range(s.num_enc_steps):
             seq += [(_lib.PH_ROUND_PROJ, r), (_lib.PH_ROUND_A, r), (_lib.PH_ROUND_B, r), (_lib.PH_ROUND_STAT, r),
@@ -169,6 +170,8 @@ class CpuPhaseBackend:
                 self.p(f"encoder.node_mlp.fc_layers.{lay.lin_slot}.bias")
             c.Y[arg] = y
             c.stat_enc_node[arg][:] = torch.cat([y.to(F64).sum(0), (y.to(F64) ** 2).sum(0)])
+        elif ph == _lib.PH_NODE_COMBINE:
+            pass
         elif ph == _lib.PH_NODE_H0:
             lay = s.enc_node[-1]
             st = c.stat_enc_node[-1]
