@@ -3,6 +3,7 @@
 // so a caller may capture a forward into a hipGraph.
 #include "kernels.h"
 
+#include <stdlib.h>
 #include <mutex>
 #include <stdarg.h>
 #include <stdio.h>
@@ -25,7 +26,7 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 struct Layout {
   mtmc_ws_layout pub;
-  size_t row32, col32, e_buf, P, Q, slab, enc_aff;
+  size_t row32, col32, e_buf[2], P, Q, slab, enc_aff;
   size_t Y[MTMC_MAX_ENC_LAYERS];
   size_t stat_enc_layer[MTMC_MAX_ENC_LAYERS];
 };
@@ -85,7 +86,8 @@ void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* lo) {
   lo->Q = take((size_t)N * 32 * sizeof(float));
   lo->row32 = take((size_t)E * sizeof(int32_t));
   lo->col32 = take((size_t)E * sizeof(int32_t));
-  lo->e_buf = take((size_t)E * 4 * sizeof(float));
+  lo->e_buf[0] = take((size_t)E * 4 * sizeof(float));
+  lo->e_buf[1] = take((size_t)E * 4 * sizeof(float));
   for (int l = 0; l < m->n_enc_layers; ++l) lo->Y[l] = take((size_t)N * m->enc_node[l].out_dim * sizeof(float));
   size_t slab = 0;                                 // split-K scratch of the node encoder (few-row graphs only)
   for (int l = 0; l < m->n_enc_layers; ++l) {
@@ -157,7 +159,8 @@ mtmc::RoundParams round_params(const Ctx& x, int r) {
   const int hn = (m->reattach_nodes ? 2 : 1) * MTMC_NODE_DIM;
   mtmc::RoundParams p;
   p.row32 = x.at<int>(x.lo.row32); p.col32 = x.at<int>(x.lo.col32);
-  p.attr = x.c->edge_attr; p.e_buf = x.at<float>(x.lo.e_buf);
+  p.attr = x.c->edge_attr;
+  p.e_buf = x.at<float>(x.lo.e_buf[r & 1]); p.e_prev = x.at<float>(x.lo.e_buf[(r + 1) & 1]);
   p.P = x.at<float>(x.lo.P); p.Q = x.at<float>(x.lo.Q);
   p.ue_w = m->upd_edge.weight; p.ue_b = m->upd_edge.bias; p.ue_g = m->upd_edge.gamma; p.ue_bt = m->upd_edge.beta;
   p.ue_ld = m->upd_edge.in_dim; p.ue_eoff = 2 * hn;

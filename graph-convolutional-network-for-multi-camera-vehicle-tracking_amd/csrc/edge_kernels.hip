@@ -118,7 +118,7 @@ __device__ __forceinline__ void edge_z1(const RoundParams& p, const EdgeEncAffin
 #pragma unroll
     for (int j = 0; j < 4; ++j) ep[j] = e0[j];
   } else {
-    const float4 v = reinterpret_cast<const float4*>(p.e_buf)[e];
+    const float4 v = reinterpret_cast<const float4*>(p.e_prev)[e];
     ep[0] = v.x; ep[1] = v.y; ep[2] = v.z; ep[3] = v.w;
   }
   const float prv[4] = {pr.x, pr.y, pr.z, pr.w}, pcv[4] = {pc.x, pc.y, pc.z, pc.w};
@@ -156,6 +156,9 @@ __global__ __launch_bounds__(256) void pass_a_kernel(RoundParams p) {
       int r;
       if (e < p.n_edges) {
         edge_z1(p, af, w, e, r, z[i]);
+        // the random 16-byte P[col] gather is what bounds this pass (one cache line per lane): do it once and
+        // hand z1 to pass B through memory instead of gathering again there
+        reinterpret_cast<float4*>(p.e_buf)[e] = make_float4(z[i][0], z[i][1], z[i][2], z[i][3]);
       } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) z[i][k] = 0.f;
@@ -172,19 +175,17 @@ __global__ __launch_bounds__(256) void pass_a_kernel(RoundParams p) {
   block_atomic_add<8>(acc, p.stats + kRoundZ1Off, kZ1Stride, red);
 }
 
+// e' = relu(bn(z1)) in place; second moments of e'; per-node segment sums of e'
 __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
-  __shared__ EdgeEncAffine af;
   __shared__ float s1[4], t1[4];
   __shared__ double red[14 * 4];
   stat_gather(p.stats + kRoundZ1Off, 8, kZ1Stride, red);
-  if (p.first_round || p.reattach_edges) edge_enc_affine_load(p.enc, &af); else __syncthreads();
+  __syncthreads();
   if (threadIdx.x < 4) {
     const int k = threadIdx.x;
     bn_affine(red[k], red[4 + k], p.e_total, p.ue_g[k], p.ue_bt[k], s1[k], t1[k]);
   }
   __syncthreads();
-  EdgeUpdWeights w;
-  load_edge_upd_weights(p, w);
   double acc[14];
 #pragma unroll
   for (int i = 0; i < 14; ++i) acc[i] = 0;
@@ -201,10 +202,12 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) vv[i][k] = 0.f;
       if (e < p.n_edges) {
-        float z[4];
-        edge_z1(p, af, w, e, rr[i], z);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) vv[i][k] = fmaxf(fmaf(z[k], s1[k], t1[k]), 0.f);
+        rr[i] = p.row32[e];
+        const float4 z = reinterpret_cast<const float4*>(p.e_buf)[e];
+        vv[i][0] = fmaxf(fmaf(z.x, s1[0], t1[0]), 0.f);
+        vv[i][1] = fmaxf(fmaf(z.y, s1[1], t1[1]), 0.f);
+        vv[i][2] = fmaxf(fmaf(z.z, s1[2], t1[2]), 0.f);
+        vv[i][3] = fmaxf(fmaf(z.w, s1[3], t1[3]), 0.f);
         reinterpret_cast<float4*>(p.e_buf)[e] = make_float4(vv[i][0], vv[i][1], vv[i][2], vv[i][3]);
       }
     }

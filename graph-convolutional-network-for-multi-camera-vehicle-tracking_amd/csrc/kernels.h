@@ -15,7 +15,9 @@ struct PrepParams {
 
 // Everything one message-passing round needs (passes A, B, C).
 struct RoundParams {
-  const int* row32; const int* col32; const float* attr; float* e_buf;
+  const int* row32; const int* col32; const float* attr;
+  const float* e_prev;       // [E][4] edge state of the previous round (unused in the first round)
+  float* e_buf;              // [E][4] this round: z1 (pass A) -> e' in place (pass B) -> read by pass C
   const float* P;            // [N][8]  Pr | Pc
   const float* Q;            // [N][32]
   const float* ue_w; const float* ue_b; const float* ue_g; const float* ue_bt; int ue_ld; int ue_eoff;
