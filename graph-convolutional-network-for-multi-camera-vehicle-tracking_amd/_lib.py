@@ -29,7 +29,8 @@ class Model(C.Structure):
     _fields_ = [("n_enc_layers", C.c_int32), ("enc_node", Layer * MAX_ENC_LAYERS), ("enc_edge", Layer * 2),
                 ("upd_edge", Layer), ("upd_node", Layer), ("cls", Layer),
                 ("agg", C.c_int32), ("num_enc_steps", C.c_int32), ("num_class_steps", C.c_int32),
-                ("reattach_nodes", C.c_int32), ("reattach_edges", C.c_int32)]
+                ("reattach_nodes", C.c_int32), ("reattach_edges", C.c_int32),
+                ("dropout_enc", C.c_float), ("dropout_upd_edge", C.c_float), ("dropout_upd_node", C.c_float)]
 
 
 class Call(C.Structure):
@@ -56,7 +57,7 @@ F_GLOBAL_DEG, F_FORK = 4, 2
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmtmc_mpn.so")
 EXPORTS = ["mtmc_mpn_abi_version", "mtmc_mpn_last_error", "mtmc_mpn_workspace_bytes", "mtmc_mpn_workspace_layout",
            "mtmc_mpn_forward", "mtmc_mpn_run_phase", "mtmc_scatter_add", "mtmc_scatter_mean", "mtmc_scatter_max",
-           "mtmc_mlp_layer_forward"]
+           "mtmc_mlp_layer_forward", "mtmc_mpn_train_workspace_bytes", "mtmc_mpn_backward"]
 
 _lib = None
 
@@ -79,6 +80,11 @@ def load() -> C.CDLL:
     lib.mtmc_mpn_workspace_layout.argtypes = [C.POINTER(Model), C.c_int64, C.c_int64, C.POINTER(WsLayout)]
     lib.mtmc_mpn_forward.restype = C.c_int32
     lib.mtmc_mpn_forward.argtypes = [C.POINTER(Model), C.POINTER(Call)]
+    lib.mtmc_mpn_train_workspace_bytes.restype = C.c_size_t
+    lib.mtmc_mpn_train_workspace_bytes.argtypes = [C.POINTER(Model), C.c_int64, C.c_int64]
+    lib.mtmc_mpn_backward.restype = C.c_int32
+    lib.mtmc_mpn_backward.argtypes = [C.POINTER(Model), C.POINTER(Call), C.c_void_p, C.c_void_p, C.POINTER(Model),
+                                      C.c_void_p, C.c_void_p]
     lib.mtmc_mpn_run_phase.restype = C.c_int32
     lib.mtmc_mpn_run_phase.argtypes = [C.POINTER(Model), C.POINTER(Call), C.c_int32, C.c_int32]
     for name in ("mtmc_scatter_add",):
@@ -93,7 +99,7 @@ def load() -> C.CDLL:
     lib.mtmc_mlp_layer_forward.restype = C.c_int32
     lib.mtmc_mlp_layer_forward.argtypes = [C.POINTER(Layer), C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                            C.c_void_p]
-    if lib.mtmc_mpn_abi_version() != 1:
+    if lib.mtmc_mpn_abi_version() != 2:
         raise RuntimeError("mtmc_mpn: ABI version mismatch between _lib.py and libmtmc_mpn.so")
     _lib = lib
     return lib

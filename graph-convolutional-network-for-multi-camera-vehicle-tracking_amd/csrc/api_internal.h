@@ -1,0 +1,376 @@
+// Internals shared by the C-ABI translation units (api.hip: forward + phases, api_train.hip: backward):
+// error text, workspace carving, per-phase parameter blocks and the phase launcher.
+#pragma once
+#include "kernels.h"
+
+#include <mutex>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+
+namespace mtmc_api {
+
+
+inline thread_local char g_err[512] = "";
+
+inline int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct Layout {
+  mtmc_ws_layout pub;
+  size_t row32, col32, e_buf[2], P, Q, slab, enc_aff;
+  size_t Y[MTMC_MAX_ENC_LAYERS];
+  size_t stat_enc_layer[MTMC_MAX_ENC_LAYERS];
+  // training: every round keeps its own buffers (the workspace is the backward tape) + backward scratch
+  bool training;
+  std::vector<size_t> z_tr, e_tr, h_tr;       // per round: z1 [E][4], e' [E][4], aggregated h [N][32]
+  size_t g_e[2], g_e0, g_h[2], g_h0, g_P, g_Q, g_dz2, g_arg;   // gradients wrt e_r, e0, h_r, h0, P, Q; dz2 [E][32]
+  size_t bst;                                  // f64[kStatRep][kBwdStride] backward statistics scratch
+  size_t gA, gB, tA, tB, tW, zeros, bst_n;     // node-encoder backward: gradient ping-pong, transposes, 0-bias, column stats
+};
+constexpr int kBwdStride = 256;                // doubles per replica of the backward statistics scratch
+
+inline int check_model(const mtmc_mpn_model* m) {
+  if (!m) return fail(MTMC_E_ARG, "model is NULL");
+  if (m->n_enc_layers < 1 || m->n_enc_layers > MTMC_MAX_ENC_LAYERS) return fail(MTMC_E_ARG, "n_enc_layers out of range");
+  for (int l = 0; l < m->n_enc_layers; ++l) {
+    const mtmc_layer& L = m->enc_node[l];
+    if (!L.weight || !L.bias || !L.gamma || !L.beta) return fail(MTMC_E_ARG, "node encoder layer %d: NULL parameter", l);
+    if (L.in_dim % 32 || L.in_dim < 32 || L.out_dim < 1) return fail(MTMC_E_ARG, "node encoder layer %d: in_dim must be a positive multiple of 32", l);
+    if (l && L.in_dim != m->enc_node[l - 1].out_dim) return fail(MTMC_E_ARG, "node encoder layer %d: in_dim != previous out_dim", l);
+  }
+  if (m->enc_node[m->n_enc_layers - 1].out_dim != MTMC_NODE_DIM) return fail(MTMC_E_ARG, "node encoder must end at width %d", MTMC_NODE_DIM);
+  if ((m->enc_edge[0].in_dim != 1 && m->enc_edge[0].in_dim != 2) || m->enc_edge[0].out_dim != 4 ||
+      m->enc_edge[1].in_dim != 4 || m->enc_edge[1].out_dim != 4)
+    return fail(MTMC_E_ARG, "edge encoder must be in(1|2)->4->4");
+  const int hn = (m->reattach_nodes ? 2 : 1) * MTMC_NODE_DIM, he = (m->reattach_edges ? 2 : 1) * MTMC_EDGE_DIM;
+  if (m->upd_edge.in_dim != 2 * hn + he || m->upd_edge.out_dim != 4) return fail(MTMC_E_ARG, "edge update layer must be [4, %d]", 2 * hn + he);
+  if (m->upd_node.in_dim != hn + 4 || m->upd_node.out_dim != MTMC_NODE_DIM) return fail(MTMC_E_ARG, "node update layer must be [32, %d]", hn + 4);
+  if (m->cls.in_dim != 4 || m->cls.out_dim < 1 || m->cls.out_dim > MTMC_MAX_CLASSES) return fail(MTMC_E_ARG, "classifier must be [C<=4, 4]");
+  const mtmc_layer* small[] = {&m->enc_edge[0], &m->enc_edge[1], &m->upd_edge, &m->upd_node};
+  for (const mtmc_layer* L : small)
+    if (!L->weight || !L->bias || !L->gamma || !L->beta) return fail(MTMC_E_ARG, "NULL parameter in an edge/update layer");
+  if (!m->cls.weight || !m->cls.bias) return fail(MTMC_E_ARG, "NULL classifier parameter");
+  if (m->agg < 0 || m->agg > 2) return fail(MTMC_E_ARG, "agg must be MTMC_AGG_SUM/MEAN/MAX");
+  if (m->num_enc_steps < 0 || m->num_class_steps < 0) return fail(MTMC_E_ARG, "negative step count");
+  return MTMC_OK;
+}
+
+inline void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* lo, bool training = false) {
+  *lo = Layout();
+  lo->training = training;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
+  const int L = m->num_enc_steps;
+  lo->pub.flags_off = take(8 * sizeof(int32_t));
+  lo->pub.stat_attr_off = take((size_t)mtmc::kStatRep * mtmc::kAttrStride * sizeof(double));
+  lo->pub.stat_enc2_off = take((size_t)mtmc::kStatRep * mtmc::kEnc2Stride * sizeof(double));
+  size_t enc_stats = 0;
+  for (int l = 0; l < m->n_enc_layers; ++l) enc_stats += 2 * (size_t)m->enc_node[l].out_dim;
+  lo->pub.stat_enc_node_off = take(enc_stats * sizeof(double));
+  size_t acc = 0;
+  for (int l = 0; l < m->n_enc_layers; ++l) {
+    lo->stat_enc_layer[l] = lo->pub.stat_enc_node_off + acc * sizeof(double);
+    acc += 2 * (size_t)m->enc_node[l].out_dim;
+  }
+  lo->pub.stat_round_off = take((size_t)(L > 0 ? L : 1) * mtmc::kRoundBlock * sizeof(double));
+  lo->pub.deg_off = take((size_t)N * sizeof(int32_t));
+  lo->pub.seg_off = take((size_t)N * 4 * sizeof(double));
+  lo->pub.zero_bytes = off;
+  lo->pub.deg_global_off = take((size_t)N * sizeof(int32_t));
+  lo->pub.h0_off = take((size_t)N * 32 * sizeof(float));
+  lo->pub.h_acc_off[0] = take((size_t)N * 32 * sizeof(float));
+  lo->pub.h_acc_off[1] = take((size_t)N * 32 * sizeof(float));
+  lo->enc_aff = take(16 * sizeof(float));
+  lo->P = take((size_t)N * 8 * sizeof(float));
+  lo->Q = take((size_t)N * 32 * sizeof(float));
+  lo->row32 = take((size_t)E * sizeof(int32_t));
+  lo->col32 = take((size_t)E * sizeof(int32_t));
+  lo->e_buf[0] = take((size_t)E * 4 * sizeof(float));
+  lo->e_buf[1] = take((size_t)E * 4 * sizeof(float));
+  for (int l = 0; l < m->n_enc_layers; ++l) lo->Y[l] = take((size_t)N * m->enc_node[l].out_dim * sizeof(float));
+  size_t slab = 0;                                 // split-K scratch of the node encoder (few-row graphs only)
+  for (int l = 0; l < m->n_enc_layers; ++l) {
+    int sk;
+    mtmc::gemm_plan(N, m->enc_node[l].in_dim, m->enc_node[l].out_dim, &sk);
+    const size_t need = sk > 1 ? (size_t)sk * N * m->enc_node[l].out_dim * sizeof(float) : 0;
+    if (need > slab) slab = need;
+  }
+  lo->slab = take(slab);
+  if (training) {
+    for (int r = 0; r < L; ++r) {
+      lo->z_tr.push_back(take((size_t)E * 4 * sizeof(float)));
+      lo->e_tr.push_back(take((size_t)E * 4 * sizeof(float)));
+      lo->h_tr.push_back(take((size_t)N * 32 * sizeof(float)));
+    }
+    for (int i = 0; i < 2; ++i) lo->g_e[i] = take((size_t)E * 4 * sizeof(float));
+    lo->g_e0 = take((size_t)E * 4 * sizeof(float));
+    for (int i = 0; i < 2; ++i) lo->g_h[i] = take((size_t)N * 32 * sizeof(float));
+    lo->g_h0 = take((size_t)N * 32 * sizeof(float));
+    lo->g_P = take((size_t)N * 8 * sizeof(float));
+    lo->g_Q = take((size_t)N * 32 * sizeof(float));
+    lo->g_dz2 = take((size_t)E * 32 * sizeof(float));
+    lo->g_arg = take((size_t)N * 32 * sizeof(int32_t));
+    lo->bst = take((size_t)mtmc::kStatRep * kBwdStride * sizeof(double));
+    size_t maxd = 0;
+    for (int l = 0; l < m->n_enc_layers; ++l) {
+      maxd = std::max(maxd, (size_t)m->enc_node[l].in_dim);
+      maxd = std::max(maxd, (size_t)m->enc_node[l].out_dim);
+    }
+    const size_t npad = (size_t)((N + 31) / 32 * 32);
+    lo->gA = take((size_t)N * maxd * sizeof(float));
+    lo->gB = take((size_t)N * maxd * sizeof(float));
+    lo->tA = take(npad * maxd * sizeof(float));
+    lo->tB = take(npad * maxd * sizeof(float));
+    lo->tW = take(maxd * maxd * sizeof(float));
+    lo->zeros = take(maxd * sizeof(float));
+    lo->bst_n = take(2 * maxd * sizeof(double));
+  }
+  lo->pub.total_bytes = off;
+}
+
+struct Ctx {
+  const mtmc_mpn_model* m;
+  const mtmc_mpn_call* c;
+  Layout lo;
+  char* ws;
+  hipStream_t stream;
+  template <typename T> T* at(size_t off) const { return reinterpret_cast<T*>(ws + off); }
+};
+
+inline int make_ctx(const mtmc_mpn_model* m, const mtmc_mpn_call* c, Ctx* ctx) {
+  if (int rc = check_model(m)) return rc;
+  if (!c) return fail(MTMC_E_ARG, "call is NULL");
+  if (c->training && (c->node_lo != 0 || c->node_hi != c->n_nodes || c->n_edges_total != c->n_edges))
+    return fail(MTMC_E_ARG, "training mode is single-shard only");
+  if (c->n_nodes < 2) return fail(MTMC_E_ROWS, "BatchNorm over %lld node rows: Expected more than 1 value per channel", (long long)c->n_nodes);
+  if (c->n_edges_total < 2) return fail(MTMC_E_ROWS, "BatchNorm over %lld edge rows: Expected more than 1 value per channel", (long long)c->n_edges_total);
+  if (c->n_edges < 0 || c->n_edges > c->n_edges_total || c->n_edges >= (1ll << 31) || c->n_nodes >= (1ll << 31))
+    return fail(MTMC_E_ARG, "edge/node counts out of range");
+  if (c->node_lo < 0 || c->node_hi < c->node_lo || c->node_hi > c->n_nodes) return fail(MTMC_E_ARG, "bad node range");
+  if (!c->x || !c->edge_attr || !c->logits || !c->h_out || !c->workspace) return fail(MTMC_E_ARG, "NULL tensor pointer");
+  if (c->n_edges > 0 && (!c->row || !c->col)) return fail(MTMC_E_ARG, "NULL edge_index pointer");
+  if (c->idx_stride < 1) return fail(MTMC_E_ARG, "idx_stride must be >= 1");
+  if (((uintptr_t)c->x & 15) || (c->x_row_stride & 3) || c->x_row_stride < m->enc_node[0].in_dim)
+    return fail(MTMC_E_ARG, "x must be 16-byte aligned with a row stride that is a multiple of 4 and >= in_dim");
+  if (((uintptr_t)c->edge_attr & 7) || ((uintptr_t)c->logits & 7) || ((uintptr_t)c->h_out & 15))
+    return fail(MTMC_E_ARG, "edge_attr/logits must be 8-byte and h_out 16-byte aligned");
+  if ((uintptr_t)c->workspace & 255) return fail(MTMC_E_WORKSPACE, "workspace must be 256-byte aligned");
+  ctx->m = m; ctx->c = c;
+  make_layout(m, c->n_nodes, c->n_edges, &ctx->lo, c->training != 0);
+  if (c->workspace_bytes < ctx->lo.pub.total_bytes)
+    return fail(MTMC_E_WORKSPACE, "workspace has %zu bytes, %zu needed", c->workspace_bytes, ctx->lo.pub.total_bytes);
+  ctx->ws = static_cast<char*>(c->workspace);
+  ctx->stream = static_cast<hipStream_t>(c->stream);
+  return MTMC_OK;
+}
+
+inline mtmc::Drop make_drop(const Ctx& x, float p) {
+  mtmc::Drop d;
+  d.on = (x.c->training && p > 0.f) ? 1 : 0;
+  d.seed = x.c->seed;
+  const double t = (double)p * 4294967296.0;
+  d.thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+  d.inv_keep = p < 1.f ? 1.f / (1.f - p) : 0.f;
+  return d;
+}
+
+inline mtmc::EdgeEncParams enc_params(const Ctx& x) {
+  mtmc::EdgeEncParams e;
+  const mtmc_layer& a = x.m->enc_edge[0];
+  const mtmc_layer& b = x.m->enc_edge[1];
+  e.w1 = a.weight; e.b1 = a.bias; e.g1 = a.gamma; e.bt1 = a.beta;
+  e.w2 = b.weight; e.b2 = b.bias; e.g2 = b.gamma; e.bt2 = b.beta;
+  e.stat_attr = x.at<double>(x.lo.pub.stat_attr_off);
+  e.stat_enc2 = x.at<double>(x.lo.pub.stat_enc2_off);
+  e.aff = x.at<float>(x.lo.enc_aff);
+  e.fe = a.in_dim;
+  e.drop = make_drop(x, x.m->dropout_enc);
+  return e;
+}
+
+// Where round r aggregates: the last round of a sum/max model writes latent_node_feats straight into h_out.
+inline float* agg_target(const Ctx& x, int r) {
+  if (x.lo.training) return x.at<float>(x.lo.h_tr[r]);
+  if (r == x.m->num_enc_steps - 1 && x.m->agg != MTMC_AGG_MEAN) return x.c->h_out;
+  return x.at<float>(x.lo.pub.h_acc_off[r & 1]);
+}
+// the (unscaled) node state round r reads: h0 for the first round, else what round r-1 aggregated
+inline float* round_h_src(const Ctx& x, int r) {
+  if (r == 0) return x.at<float>(x.lo.pub.h0_off);
+  return x.lo.training ? x.at<float>(x.lo.h_tr[r - 1]) : x.at<float>(x.lo.pub.h_acc_off[(r - 1) & 1]);
+}
+inline float* round_z(const Ctx& x, int r) { return x.at<float>(x.lo.training ? x.lo.z_tr[r] : x.lo.e_buf[r & 1]); }
+inline float* round_e(const Ctx& x, int r) { return x.at<float>(x.lo.training ? x.lo.e_tr[r] : x.lo.e_buf[r & 1]); }
+
+inline mtmc::RoundParams round_params(const Ctx& x, int r) {
+  const mtmc_mpn_model* m = x.m;
+  const int hn = (m->reattach_nodes ? 2 : 1) * MTMC_NODE_DIM;
+  mtmc::RoundParams p;
+  p.row32 = x.at<int>(x.lo.row32); p.col32 = x.at<int>(x.lo.col32);
+  p.attr = x.c->edge_attr;
+  p.e_buf = round_z(x, r); p.e_out = round_e(x, r); p.e_prev = r > 0 ? round_e(x, r - 1) : nullptr;
+  p.drop_e = make_drop(x, m->dropout_upd_edge); p.drop_n = make_drop(x, m->dropout_upd_node);
+  p.drop_stream = mtmc::kDropRound + 2 * r;
+  p.P = x.at<float>(x.lo.P); p.Q = x.at<float>(x.lo.Q);
+  p.ue_w = m->upd_edge.weight; p.ue_b = m->upd_edge.bias; p.ue_g = m->upd_edge.gamma; p.ue_bt = m->upd_edge.beta;
+  p.ue_ld = m->upd_edge.in_dim; p.ue_eoff = 2 * hn;
+  p.un_w = m->upd_node.weight; p.un_b = m->upd_node.bias; p.un_g = m->upd_node.gamma; p.un_bt = m->upd_node.beta;
+  p.un_ld = m->upd_node.in_dim; p.un_eoff = hn;
+  p.cls_w = m->cls.weight; p.cls_b = m->cls.bias; p.n_classes = m->cls.out_dim;
+  p.stats = x.at<double>(x.lo.pub.stat_round_off) + (size_t)r * mtmc::kRoundBlock;
+  p.seg = x.at<double>(x.lo.pub.seg_off);
+  p.h_acc = agg_target(x, r);
+  const int step = r + 1;
+  int first_cls = m->num_enc_steps - m->num_class_steps + 1;   // mpn.py:277; Cs > L classifies every round
+  if (first_cls < 1) first_cls = 1;
+  p.logits = step >= first_cls ? x.c->logits + (size_t)(step - first_cls) * x.c->n_edges * m->cls.out_dim : nullptr;
+  p.n_edges = x.c->n_edges; p.e_total = (double)x.c->n_edges_total;
+  p.first_round = r == 0; p.reattach_edges = m->reattach_edges; p.agg = m->agg;
+  p.enc = enc_params(x);
+  return p;
+}
+
+enum { kPhMemset = -1, kPhPrep = -2 };   // the two halves of MTMC_PH_BEGIN, for the forked forward
+
+inline const int* scale_deg(const Ctx& x) {   // the degree mean aggregation divides by
+  return x.at<int>((x.c->flags & MTMC_F_GLOBAL_DEG) ? x.lo.pub.deg_global_off : x.lo.pub.deg_off);
+}
+
+inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
+  const mtmc_mpn_model* m = x.m;
+  const mtmc_mpn_call* c = x.c;
+  const int L = m->num_enc_steps;
+  hipStream_t s = x.stream;
+  switch (phase) {
+    case MTMC_PH_BEGIN:
+    case kPhMemset:
+    case kPhPrep: {
+      if (phase != kPhPrep && hipMemsetAsync(x.ws, 0, x.lo.pub.zero_bytes, s) != hipSuccess)
+        return fail(MTMC_E_HIP, "hipMemsetAsync failed");
+      if (phase != kPhMemset && c->n_edges > 0) {
+        mtmc::PrepParams p;
+        p.row = c->row; p.col = c->col; p.idx_stride = c->idx_stride; p.attr = c->edge_attr; p.fe = m->enc_edge[0].in_dim;
+        p.n_edges = c->n_edges; p.n_nodes = c->n_nodes;
+        p.row32 = x.at<int>(x.lo.row32); p.col32 = x.at<int>(x.lo.col32); p.deg = x.at<int>(x.lo.pub.deg_off);
+        p.flags = x.at<int>(x.lo.pub.flags_off); p.stat_attr = x.at<double>(x.lo.pub.stat_attr_off);
+        mtmc::launch_prep(p, s);
+      }
+      break;
+    }
+    case MTMC_PH_EDGE_ENC:
+      if (c->n_edges > 0)
+        mtmc::launch_enc2(enc_params(x), c->edge_attr, c->n_edges, (double)c->n_edges_total, x.at<double>(x.lo.pub.stat_enc2_off), s);
+      break;
+    case MTMC_PH_NODE_ENC:
+    case MTMC_PH_NODE_COMBINE: {
+      if (arg < 0 || arg >= m->n_enc_layers) return fail(MTMC_E_ARG, "encoder layer %d out of range", arg);
+      const int64_t rows = c->node_hi - c->node_lo;
+      if (rows == 0) break;
+      const mtmc_layer& Lr = m->enc_node[arg];
+      mtmc::GemmParams g;
+      if (arg == 0) {
+        g.A = c->x; g.lda = c->x_row_stride; g.stats_in = nullptr; g.gamma_in = nullptr; g.beta_in = nullptr;
+      } else {
+        g.A = x.at<float>(x.lo.Y[arg - 1]); g.lda = m->enc_node[arg - 1].out_dim;
+        g.stats_in = x.at<double>(x.lo.stat_enc_layer[arg - 1]);
+        g.gamma_in = m->enc_node[arg - 1].gamma; g.beta_in = m->enc_node[arg - 1].beta;
+      }
+      g.W = Lr.weight; g.bias = Lr.bias; g.Y = x.at<float>(x.lo.Y[arg]); g.ldy = Lr.out_dim;
+      g.count = (double)c->n_nodes; g.stats_out = x.at<double>(x.lo.stat_enc_layer[arg]);
+      g.M = rows; g.K = Lr.in_dim; g.Nout = Lr.out_dim;
+      g.drop_in = make_drop(x, m->dropout_enc); g.drop_stream = mtmc::kDropEncNode + arg - 1;
+      {  // the slab was sized for N rows; a shard with fewer rows may plan a larger split
+        int sk_full, sk_here;
+        mtmc::gemm_plan(c->n_nodes, g.K, g.Nout, &sk_full);
+        mtmc::gemm_plan(rows, g.K, g.Nout, &sk_here);
+        g.slab = (sk_here > 1 && (size_t)sk_here * rows <= (size_t)(sk_full > 1 ? sk_full : 0) * c->n_nodes)
+                     ? x.at<float>(x.lo.slab) : nullptr;
+        g.split_k = 1;
+      }
+      if (mtmc::launch_gemm_bn(g, s, phase == MTMC_PH_NODE_ENC ? 1 : 2) != MTMC_OK)
+        return fail(MTMC_E_ARG, "encoder layer %d: unsupported GEMM shape", arg);
+      break;
+    }
+    case MTMC_PH_NODE_H0: {
+      const int last = m->n_enc_layers - 1;
+      const int64_t rows = c->node_hi - c->node_lo;
+      if (rows > 0)
+        mtmc::launch_bn_relu_rows(x.at<float>(x.lo.Y[last]), MTMC_NODE_DIM, rows, MTMC_NODE_DIM,
+                                  x.at<double>(x.lo.stat_enc_layer[last]), m->enc_node[last].gamma, m->enc_node[last].beta,
+                                  (double)c->n_nodes, x.at<float>(x.lo.pub.h0_off) + (size_t)c->node_lo * MTMC_NODE_DIM,
+                                  make_drop(x, m->dropout_enc), mtmc::kDropEncNode + last, c->node_lo, s);
+      break;
+    }
+    case MTMC_PH_ROUND_PROJ: {
+      if (arg < 0 || arg >= L) return fail(MTMC_E_ARG, "round %d out of range", arg);
+      mtmc::NodeProjParams p;
+      const int last = m->n_enc_layers - 1;
+      p.y_last = (arg == 0 && fused_h0) ? x.at<float>(x.lo.Y[last]) : nullptr;
+      p.y_stats = x.at<double>(x.lo.stat_enc_layer[last]); p.y_gamma = m->enc_node[last].gamma;
+      p.y_beta = m->enc_node[last].beta; p.y_count = (double)c->n_nodes; p.h0_out = x.at<float>(x.lo.pub.h0_off);
+      p.finalize_enc = arg == 0; p.enc = enc_params(x); p.e_total = (double)c->n_edges_total;
+      p.h_src = round_h_src(x, arg);
+      p.drop = make_drop(x, m->dropout_enc); p.drop_stream = mtmc::kDropEncNode + last;
+      p.h0 = m->reattach_nodes ? x.at<float>(x.lo.pub.h0_off) : nullptr;
+      p.deg = (m->agg == MTMC_AGG_MEAN && arg > 0) ? scale_deg(x) : nullptr;
+      p.ue_w = m->upd_edge.weight; p.ue_ld = m->upd_edge.in_dim;
+      p.un_w = m->upd_node.weight; p.un_ld = m->upd_node.in_dim;
+      p.hn = (m->reattach_nodes ? 2 : 1) * MTMC_NODE_DIM;
+      p.P = x.at<float>(x.lo.P); p.Q = x.at<float>(x.lo.Q);
+      p.zero_buf = agg_target(x, arg);
+      p.n_nodes = c->n_nodes;
+      mtmc::launch_node_proj(p, s);
+      break;
+    }
+    case MTMC_PH_ROUND_A:
+    case MTMC_PH_ROUND_B:
+    case MTMC_PH_ROUND_C: {
+      if (arg < 0 || arg >= L) return fail(MTMC_E_ARG, "round %d out of range", arg);
+      if (c->n_edges == 0) break;
+      const mtmc::RoundParams p = round_params(x, arg);
+      if (phase == MTMC_PH_ROUND_A) mtmc::launch_pass_a(p, s);
+      else if (phase == MTMC_PH_ROUND_B) mtmc::launch_pass_b(p, s);
+      else mtmc::launch_pass_c(p, s);
+      break;
+    }
+    case MTMC_PH_ROUND_STAT: {
+      if (arg < 0 || arg >= L) return fail(MTMC_E_ARG, "round %d out of range", arg);
+      mtmc::NodeStatParams p;
+      p.Q = x.at<float>(x.lo.Q); p.deg = x.at<int>(x.lo.pub.deg_off); p.seg = x.at<double>(x.lo.pub.seg_off);
+      p.un_w = m->upd_node.weight; p.un_b = m->upd_node.bias; p.un_ld = m->upd_node.in_dim;
+      p.un_eoff = (m->reattach_nodes ? 2 : 1) * MTMC_NODE_DIM;
+      p.stats = x.at<double>(x.lo.pub.stat_round_off) + (size_t)arg * mtmc::kRoundBlock;
+      p.n_nodes = c->n_nodes;
+      mtmc::launch_node_stat(p, s);
+      break;
+    }
+    case MTMC_PH_END: {
+      const float* src = round_h_src(x, L);
+      if (L == 0 || m->agg == MTMC_AGG_MEAN || x.lo.training)   // otherwise the last round aggregated into h_out
+        mtmc::launch_h_final(src, scale_deg(x), (m->agg == MTMC_AGG_MEAN && L > 0) ? 1 : 0, c->n_nodes, c->h_out, s);
+      if (L == 0 && c->n_edges > 0)
+        mtmc::launch_classify_e0(enc_params(x), c->edge_attr, c->n_edges, (double)c->n_edges_total, m->cls.weight,
+                                 m->cls.bias, m->cls.out_dim, c->logits, s);
+      break;
+    }
+    default:
+      return fail(MTMC_E_ARG, "unknown phase %d", phase);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MTMC_E_HIP, "kernel launch failed in phase %d: %s", phase, hipGetErrorString(e));
+  return MTMC_OK;
+}
+
+}  // namespace mtmc_api

@@ -1,0 +1,205 @@
+// C-ABI entry point of the backward pass (include/mtmc_mpn.h: mtmc_mpn_backward).  Launch-only, like the forward.
+// Order: rounds L-1..0 (node-update MLP, edge-update MLP + classifier, node projections), then the edge encoder,
+// then the node encoder (BatchNorm backward + two fp32-MFMA GEMMs per layer on transposed operands).
+#include "api_internal.h"
+#include "train_kernels.h"
+
+using namespace mtmc_api;
+
+namespace {
+
+#define HIP_OK(call)                                                                                   \
+  do {                                                                                                 \
+    if ((call) != hipSuccess) return fail(MTMC_E_HIP, "%s failed in mtmc_mpn_backward", #call);        \
+  } while (0)
+
+int check_grads(const mtmc_mpn_model* m, const mtmc_mpn_model* g) {
+  if (!g) return fail(MTMC_E_ARG, "grads is NULL");
+  for (int l = 0; l < m->n_enc_layers; ++l)
+    if (!g->enc_node[l].weight || !g->enc_node[l].bias || !g->enc_node[l].gamma || !g->enc_node[l].beta)
+      return fail(MTMC_E_ARG, "grads: NULL node-encoder gradient buffer");
+  const mtmc_layer* ls[] = {&g->enc_edge[0], &g->enc_edge[1], &g->upd_edge, &g->upd_node};
+  for (const mtmc_layer* l : ls)
+    if (!l->weight || !l->bias || !l->gamma || !l->beta) return fail(MTMC_E_ARG, "grads: NULL gradient buffer");
+  if (!g->cls.weight || !g->cls.bias) return fail(MTMC_E_ARG, "grads: NULL classifier gradient buffer");
+  return MTMC_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t mtmc_mpn_backward(const mtmc_mpn_model* model, const mtmc_mpn_call* call, const float* d_logits,
+                                     const float* d_h, const mtmc_mpn_model* grads, float* d_x, float* d_edge_attr) {
+  Ctx x;
+  if (int rc = make_ctx(model, call, &x)) return rc;
+  if (!call->training) return fail(MTMC_E_ARG, "mtmc_mpn_backward needs the call of a training-mode forward");
+  if (int rc = check_grads(model, grads)) return rc;
+  const mtmc_mpn_model* m = model;
+  const int L = m->num_enc_steps;
+  if (L < 1) return fail(MTMC_E_ARG, "backward with num_enc_steps == 0 is not implemented");
+  const int64_t N = call->n_nodes, E = call->n_edges;
+  const int hn = (m->reattach_nodes ? 2 : 1) * MTMC_NODE_DIM;
+  const int C = m->cls.out_dim;
+  hipStream_t s = x.stream;
+  const Layout& lo = x.lo;
+  double* bst = x.at<double>(lo.bst);
+  const size_t bst_bytes = (size_t)mtmc::kStatRep * kBwdStride * sizeof(double);
+  float* g_e[2] = {x.at<float>(lo.g_e[0]), x.at<float>(lo.g_e[1])};
+  float* g_h[2] = {x.at<float>(lo.g_h[0]), x.at<float>(lo.g_h[1])};
+  float* g_e0 = x.at<float>(lo.g_e0);
+  float* g_h0 = x.at<float>(lo.g_h0);
+
+  // gradient buffers are accumulated into with atomics: clear them first (the caller only provides storage)
+  auto zero = [&](float* p, size_t n) { return hipMemsetAsync(p, 0, n * sizeof(float), s); };
+  for (int l = 0; l < m->n_enc_layers; ++l) {
+    const mtmc_layer& g = grads->enc_node[l];
+    const size_t o = m->enc_node[l].out_dim, i = m->enc_node[l].in_dim;
+    HIP_OK(zero(const_cast<float*>(g.weight), o * i)); HIP_OK(zero(const_cast<float*>(g.bias), o));
+    HIP_OK(zero(const_cast<float*>(g.gamma), o)); HIP_OK(zero(const_cast<float*>(g.beta), o));
+  }
+  {
+    const mtmc_layer* gs[] = {&grads->enc_edge[0], &grads->enc_edge[1], &grads->upd_edge, &grads->upd_node, &grads->cls};
+    const mtmc_layer* ms[] = {&m->enc_edge[0], &m->enc_edge[1], &m->upd_edge, &m->upd_node, &m->cls};
+    for (int i = 0; i < 5; ++i) {
+      const size_t o = ms[i]->out_dim, in = ms[i]->in_dim;
+      HIP_OK(zero(const_cast<float*>(gs[i]->weight), o * in)); HIP_OK(zero(const_cast<float*>(gs[i]->bias), o));
+      if (i < 4) { HIP_OK(zero(const_cast<float*>(gs[i]->gamma), o)); HIP_OK(zero(const_cast<float*>(gs[i]->beta), o)); }
+    }
+  }
+  HIP_OK(zero(g_e[0], (size_t)E * 4)); HIP_OK(zero(g_e0, (size_t)E * 4)); HIP_OK(zero(g_h0, (size_t)N * 32));
+  int cur = 0, cur_e = 0;
+  if (d_h) HIP_OK(hipMemcpyAsync(g_h[cur], d_h, (size_t)N * 32 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  else HIP_OK(zero(g_h[cur], (size_t)N * 32));
+
+  int first_cls = L - m->num_class_steps + 1;
+  if (first_cls < 1) first_cls = 1;
+
+  for (int r = L - 1; r >= 0; --r) {
+    // P, Q of this round again (same kernel as the forward; h0 and the round inputs are on the tape)
+    mtmc::NodeProjParams np;
+    np.y_last = nullptr; np.y_stats = nullptr; np.y_gamma = nullptr; np.y_beta = nullptr; np.y_count = 1; np.h0_out = nullptr;
+    np.finalize_enc = 0; np.enc = enc_params(x); np.e_total = (double)E;
+    np.drop = make_drop(x, 0.f); np.drop_stream = 0;
+    np.h_src = round_h_src(x, r);
+    np.h0 = m->reattach_nodes ? x.at<float>(lo.pub.h0_off) : nullptr;
+    np.deg = (m->agg == MTMC_AGG_MEAN && r > 0) ? x.at<int>(lo.pub.deg_off) : nullptr;
+    np.ue_w = m->upd_edge.weight; np.ue_ld = m->upd_edge.in_dim; np.un_w = m->upd_node.weight; np.un_ld = m->upd_node.in_dim;
+    np.hn = hn; np.P = x.at<float>(lo.P); np.Q = x.at<float>(lo.Q); np.zero_buf = nullptr; np.n_nodes = N;
+    mtmc::launch_node_proj(np, s);
+
+    mtmc::BwdRoundParams bp;
+    bp.f = round_params(x, r);
+    bp.g_h = g_h[cur]; bp.h_agg = x.at<float>(lo.h_tr[r]); bp.deg = x.at<int>(lo.pub.deg_off);
+    bp.arg = x.at<int>(lo.g_arg);
+    const int step = r + 1;
+    bp.d_logits = (d_logits && step >= first_cls) ? d_logits + (size_t)(step - first_cls) * E * C : nullptr;
+    bp.g_dz2 = x.at<float>(lo.g_dz2); bp.g_Q = x.at<float>(lo.g_Q); bp.g_P = x.at<float>(lo.g_P);
+    bp.g_e = g_e[cur_e]; bp.g_e_prev = g_e[cur_e ^ 1]; bp.g_e0 = g_e0; bp.bst = bst;
+    bp.gr_un_w = const_cast<float*>(grads->upd_node.weight); bp.gr_un_b = const_cast<float*>(grads->upd_node.bias);
+    bp.gr_un_g = const_cast<float*>(grads->upd_node.gamma); bp.gr_un_bt = const_cast<float*>(grads->upd_node.beta);
+    bp.gr_ue_w = const_cast<float*>(grads->upd_edge.weight); bp.gr_ue_b = const_cast<float*>(grads->upd_edge.bias);
+    bp.gr_ue_g = const_cast<float*>(grads->upd_edge.gamma); bp.gr_ue_bt = const_cast<float*>(grads->upd_edge.beta);
+    bp.gr_cls_w = const_cast<float*>(grads->cls.weight); bp.gr_cls_b = const_cast<float*>(grads->cls.bias);
+
+    HIP_OK(zero(bp.g_Q, (size_t)N * 32)); HIP_OK(zero(bp.g_P, (size_t)N * 8));
+    HIP_OK(hipMemsetAsync(bst, 0, bst_bytes, s));
+    if (m->agg == MTMC_AGG_MAX) {
+      HIP_OK(hipMemsetAsync(bp.arg, 0x7f, (size_t)N * 32 * sizeof(int32_t), s));
+      mtmc::launch_bwd_node_upd(bp, 2, s);
+    }
+    mtmc::launch_bwd_node_upd(bp, 0, s);
+    mtmc::launch_bwd_node_upd(bp, 1, s);
+    HIP_OK(hipMemsetAsync(bst, 0, bst_bytes, s));
+    mtmc::launch_bwd_edge_upd(bp, 0, s);
+    mtmc::launch_bwd_edge_upd(bp, 1, s);
+
+    mtmc::BwdProjParams pp;
+    pp.g_P = bp.g_P; pp.g_Q = bp.g_Q; pp.h_src = np.h_src; pp.h0 = np.h0; pp.deg = np.deg;
+    pp.ue_w = np.ue_w; pp.ue_ld = np.ue_ld; pp.un_w = np.un_w; pp.un_ld = np.un_ld; pp.hn = hn;
+    pp.g_h_prev = g_h[cur ^ 1]; pp.g_h0 = g_h0; pp.src_is_h0 = r == 0;
+    pp.gr_ue_w = bp.gr_ue_w; pp.gr_un_w = bp.gr_un_w; pp.n_nodes = N;
+    mtmc::launch_bwd_node_proj(pp, s);
+    cur ^= 1;
+    cur_e ^= 1;
+  }
+
+  // ---- edge encoder -------------------------------------------------------------------------------
+  {
+    mtmc::BwdEncParams ep;
+    ep.enc = enc_params(x); ep.attr = call->edge_attr; ep.n_edges = E; ep.e_total = (double)E; ep.g_e0 = g_e0;
+    ep.bst = bst; ep.d_attr = d_edge_attr;
+    ep.gr_w1 = const_cast<float*>(grads->enc_edge[0].weight); ep.gr_b1 = const_cast<float*>(grads->enc_edge[0].bias);
+    ep.gr_g1 = const_cast<float*>(grads->enc_edge[0].gamma); ep.gr_bt1 = const_cast<float*>(grads->enc_edge[0].beta);
+    ep.gr_w2 = const_cast<float*>(grads->enc_edge[1].weight); ep.gr_b2 = const_cast<float*>(grads->enc_edge[1].bias);
+    ep.gr_g2 = const_cast<float*>(grads->enc_edge[1].gamma); ep.gr_bt2 = const_cast<float*>(grads->enc_edge[1].beta);
+    HIP_OK(hipMemsetAsync(bst, 0, bst_bytes, s));
+    for (int pass = 0; pass < 3; ++pass) mtmc::launch_bwd_edge_enc(ep, pass, s);
+  }
+
+  // ---- node encoder -------------------------------------------------------------------------------
+  {
+    float* gA = x.at<float>(lo.gA);
+    float* gB = x.at<float>(lo.gB);
+    float* tA = x.at<float>(lo.tA);
+    float* tB = x.at<float>(lo.tB);
+    float* tW = x.at<float>(lo.tW);
+    float* zeros = x.at<float>(lo.zeros);
+    const int64_t npad = (N + 31) / 32 * 32;
+    size_t maxd = 0;
+    for (int l = 0; l < m->n_enc_layers; ++l) maxd = std::max(maxd, (size_t)std::max(m->enc_node[l].in_dim, m->enc_node[l].out_dim));
+    HIP_OK(zero(zeros, maxd));
+    HIP_OK(hipMemcpyAsync(gA, g_h0, (size_t)N * 32 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    const mtmc::Drop nodrop = {0, 0, 1.f, 0};
+    for (int l = m->n_enc_layers - 1; l >= 0; --l) {
+      const mtmc_layer& Lr = m->enc_node[l];
+      const int d = Lr.out_dim, in = Lr.in_dim;
+      double* sb = x.at<double>(lo.bst_n);
+      HIP_OK(hipMemsetAsync(sb, 0, (size_t)2 * d * sizeof(double), s));
+      mtmc::BnBwdParams bb;
+      bb.Y = x.at<float>(lo.Y[l]); bb.dA = gA; bb.rows = N; bb.dim = d;
+      bb.stats_fwd = x.at<double>(lo.stat_enc_layer[l]); bb.stats_bwd = sb; bb.count = (double)N;
+      bb.gamma = Lr.gamma; bb.beta = Lr.beta; bb.drop = make_drop(x, m->dropout_enc); bb.drop_stream = mtmc::kDropEncNode + l;
+      bb.gr_gamma = const_cast<float*>(grads->enc_node[l].gamma); bb.gr_beta = const_cast<float*>(grads->enc_node[l].beta);
+      bb.gr_bias = const_cast<float*>(grads->enc_node[l].bias);
+      mtmc::launch_bn_bwd(bb, 0, s);
+      mtmc::launch_bn_bwd(bb, 1, s);                                   // gA now holds dY_l
+      // the layer's input activation a_{l-1}: x itself, or relu(bn(Y_{l-1})) with its dropout mask
+      const float* a_in = call->x;
+      int64_t lda = call->x_row_stride;
+      if (l > 0) {
+        const mtmc_layer& Pv = m->enc_node[l - 1];
+        mtmc::launch_bn_relu_rows(x.at<float>(lo.Y[l - 1]), Pv.out_dim, N, Pv.out_dim, x.at<double>(lo.stat_enc_layer[l - 1]),
+                                  Pv.gamma, Pv.beta, (double)N, gB, make_drop(x, m->dropout_enc), mtmc::kDropEncNode + l - 1, 0, s);
+        a_in = gB; lda = in;
+      }
+      // dW_l [d][in] = dY^T . a  -> NT GEMM on the transposes (reduction over the node rows, padded to 32)
+      mtmc::launch_transpose_pad(gA, N, d, d, tA, npad, s);
+      mtmc::launch_transpose_pad(a_in, N, in, lda, tB, npad, s);
+      mtmc::GemmParams g;
+      g.A = tA; g.lda = npad; g.W = tB; g.bias = zeros; g.Y = const_cast<float*>(grads->enc_node[l].weight); g.ldy = in;
+      g.stats_in = nullptr; g.gamma_in = nullptr; g.beta_in = nullptr; g.count = 1; g.stats_out = nullptr;
+      g.M = d; g.K = (int)npad; g.Nout = in; g.drop_in = nodrop; g.drop_stream = 0; g.slab = nullptr; g.split_k = 1;
+      if (mtmc::launch_gemm_bn(g, s) != MTMC_OK) return fail(MTMC_E_ARG, "backward: weight-gradient GEMM shape");
+      // dA_{l-1} [N][in] = dY . W_l  -> NT GEMM against W^T
+      if (l > 0 || d_x) {
+        mtmc::launch_transpose_pad(Lr.weight, d, in, in, tW, d, s);   // tW [in][d]
+        g.A = gA; g.lda = d; g.W = tW; g.Y = l > 0 ? gB : d_x; g.ldy = in; g.M = N; g.K = d; g.Nout = in;
+        if (mtmc::launch_gemm_bn(g, s) != MTMC_OK) return fail(MTMC_E_ARG, "backward: input-gradient GEMM shape");
+        std::swap(gA, gB);
+      }
+    }
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MTMC_E_HIP, "kernel launch failed in backward: %s", hipGetErrorString(e));
+  return MTMC_OK;
+}
+
+// Development aid (not in the public header): byte offsets of tape regions for round `r` in the training layout.
+extern "C" int32_t mtmc_debug_tape_offsets(const mtmc_mpn_model* model, int64_t n, int64_t e, int32_t r, size_t* out) {
+  if (check_model(model) != MTMC_OK) return MTMC_E_ARG;
+  Layout lo;
+  make_layout(model, n, e, &lo, true);
+  if (r < 0 || r >= (int)lo.h_tr.size()) return MTMC_E_ARG;
+  out[0] = lo.P; out[1] = lo.Q; out[2] = lo.e_tr[r]; out[3] = lo.z_tr[r]; out[4] = lo.h_tr[r];
+  out[5] = lo.g_Q; out[6] = lo.g_dz2; out[7] = lo.g_h[0]; out[8] = lo.g_h[1]; out[9] = lo.row32; out[10] = lo.pub.h0_off;
+  return MTMC_OK;
+}

@@ -87,6 +87,28 @@ __device__ __forceinline__ void bn_affine(double sum, double sumsq, double count
   t = (float)fma(-mean, sd, (double)beta);
 }
 
+// Dropout (training mode only; reference models/mlp.py:21-22): counter-based, so any kernel -- forward or
+// backward, or the CPU model in tests/ -- regenerates the same mask from (seed, stream, element index).
+// keep iff hash >= thresh, thresh = p * 2^32; kept values are scaled by 1/(1-p).
+struct Drop { unsigned long long seed; unsigned thresh; float inv_keep; int on; };
+
+__host__ __device__ __forceinline__ unsigned drop_hash(unsigned long long seed, unsigned stream, unsigned long long idx) {
+  unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull + (unsigned long long)stream * 0xBF58476D1CE4E5B9ull;
+  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+  z ^= z >> 27; z *= 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (unsigned)(z >> 32);
+}
+__device__ __forceinline__ bool drop_keep(const Drop& d, unsigned stream, unsigned long long idx) {
+  return !d.on || drop_hash(d.seed, stream, idx) >= d.thresh;
+}
+__device__ __forceinline__ float drop_apply(const Drop& d, unsigned stream, unsigned long long idx, float v) {
+  if (!d.on) return v;
+  return drop_hash(d.seed, stream, idx) >= d.thresh ? v * d.inv_keep : 0.f;
+}
+// stream ids
+constexpr unsigned kDropEncEdge1 = 1, kDropEncEdge2 = 2, kDropEncNode = 100, kDropRound = 1000;   // +layer / +2r(+1)
+
 // Small per-launch parameter blocks, read through uniform (scalar) loads.
 struct EdgeEncParams {      // encoder.edge_mlp: in(1|2) -> 4 -> 4
   const float* w1; const float* b1; const float* g1; const float* bt1;
@@ -95,6 +117,7 @@ struct EdgeEncParams {      // encoder.edge_mlp: in(1|2) -> 4 -> 4
   const double* stat_enc2;  // f64[kStatRep][kEnc2Stride]
   float* aff;               // f32[16] = EdgeEncAffine, finalised once per forward by node_proj_kernel (round 0)
   int fe;                   // edge_in_dim (1 or 2)
+  Drop drop;                // encoder dropout (training)
 };
 
 // Affine coefficients of the two edge-encoder BatchNorms, derived from moments:
@@ -148,25 +171,25 @@ __device__ __forceinline__ void edge_enc_affine_load(const EdgeEncParams& p, Edg
 }
 
 // u = relu(bn1(W1 a + b1)) : hidden layer of the edge encoder
-__device__ __forceinline__ void edge_enc_hidden(const EdgeEncParams& p, const EdgeEncAffine& af, float a0, float a1,
-                                                float (&u)[4]) {
+__device__ __forceinline__ void edge_enc_hidden(const EdgeEncParams& p, const EdgeEncAffine& af, int64_t e, float a0,
+                                                float a1, float (&u)[4]) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     float z = p.b1[k] + p.w1[k * p.fe] * a0;
     if (p.fe > 1) z = fmaf(p.w1[k * p.fe + 1], a1, z);
-    u[k] = fmaxf(fmaf(z, af.s1[k], af.t1[k]), 0.f);
+    u[k] = drop_apply(p.drop, kDropEncEdge1, (unsigned long long)e * 4 + k, fmaxf(fmaf(z, af.s1[k], af.t1[k]), 0.f));
   }
 }
 
 // e0 = relu(bn2(W2 u + b2)) : output of the edge encoder
-__device__ __forceinline__ void edge_enc_out(const EdgeEncParams& p, const EdgeEncAffine& af, const float (&u)[4],
-                                             float (&e)[4]) {
+__device__ __forceinline__ void edge_enc_out(const EdgeEncParams& p, const EdgeEncAffine& af, int64_t eidx,
+                                             const float (&u)[4], float (&e)[4]) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     float z = p.b2[k];
 #pragma unroll
     for (int j = 0; j < 4; ++j) z = fmaf(p.w2[k * 4 + j], u[j], z);
-    e[k] = fmaxf(fmaf(z, af.s2[k], af.t2[k]), 0.f);
+    e[k] = drop_apply(p.drop, kDropEncEdge2, (unsigned long long)eidx * 4 + k, fmaxf(fmaf(z, af.s2[k], af.t2[k]), 0.f));
   }
 }
 

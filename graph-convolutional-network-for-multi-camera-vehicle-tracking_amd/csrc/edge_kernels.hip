@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void enc2_kernel(EdgeEncParams enc, const floa
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += nthreads) {
     float a0, a1, u[4];
     load_attr(attr, enc.fe, e, a0, a1);
-    edge_enc_hidden(enc, af, a0, a1, u);
+    edge_enc_hidden(enc, af, e, a0, a1, u);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       acc[i] += u[i];
@@ -111,8 +111,8 @@ __device__ __forceinline__ void edge_z1(const RoundParams& p, const EdgeEncAffin
   if (p.first_round || p.reattach_edges) {
     float a0, a1, u[4];
     load_attr(p.attr, p.enc.fe, e, a0, a1);
-    edge_enc_hidden(p.enc, af, a0, a1, u);
-    edge_enc_out(p.enc, af, u, e0);
+    edge_enc_hidden(p.enc, af, e, a0, a1, u);
+    edge_enc_out(p.enc, af, e, u, e0);
   }
   if (p.first_round) {
 #pragma unroll
@@ -204,11 +204,11 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
       if (e < p.n_edges) {
         rr[i] = p.row32[e];
         const float4 z = reinterpret_cast<const float4*>(p.e_buf)[e];
-        vv[i][0] = fmaxf(fmaf(z.x, s1[0], t1[0]), 0.f);
-        vv[i][1] = fmaxf(fmaf(z.y, s1[1], t1[1]), 0.f);
-        vv[i][2] = fmaxf(fmaf(z.z, s1[2], t1[2]), 0.f);
-        vv[i][3] = fmaxf(fmaf(z.w, s1[3], t1[3]), 0.f);
-        reinterpret_cast<float4*>(p.e_buf)[e] = make_float4(vv[i][0], vv[i][1], vv[i][2], vv[i][3]);
+        const float zz[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          vv[i][k] = drop_apply(p.drop_e, p.drop_stream, (unsigned long long)e * 4 + k, fmaxf(fmaf(zz[k], s1[k], t1[k]), 0.f));
+        reinterpret_cast<float4*>(p.e_out)[e] = make_float4(vv[i][0], vv[i][1], vv[i][2], vv[i][3]);
       }
     }
 #pragma unroll
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void pass_c_kernel(RoundParams p) {
     const int64_t e = base + threadIdx.x;
     float4 ev = make_float4(0, 0, 0, 0);
     if (e < p.n_edges) {
-      ev = reinterpret_cast<const float4*>(p.e_buf)[e];
+      ev = reinterpret_cast<const float4*>(p.e_out)[e];
       tile_row[threadIdx.x] = p.row32[e];
       if (p.logits) {                                         // classifier on this edge (mpn.py:291-292)
         float lg[MTMC_MAX_CLASSES];
@@ -321,7 +321,8 @@ __global__ __launch_bounds__(256) void pass_c_kernel(RoundParams p) {
         acc = 0.f;
         c0 = fmaf(sk, p.Q[(int64_t)r * kH + k], cb);
       }
-      const float m = fmaxf(fmaf(a4[3], v.w, fmaf(a4[2], v.z, fmaf(a4[1], v.y, fmaf(a4[0], v.x, c0)))), 0.f);
+      float m = fmaxf(fmaf(a4[3], v.w, fmaf(a4[2], v.z, fmaf(a4[1], v.y, fmaf(a4[0], v.x, c0)))), 0.f);
+      m = drop_apply(p.drop_n, p.drop_stream + 1, (unsigned long long)(base + hw * 32 + j) * kH + k, m);
       acc = (p.agg == 2) ? fmaxf(acc, m) : acc + m;
     }
     if (cur >= 0) flush_node(p, cur, k, acc);
@@ -339,8 +340,8 @@ __global__ __launch_bounds__(256) void classify_e0_kernel(EdgeEncParams enc, con
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += nthreads) {
     float a0, a1, u[4], e0[4];
     load_attr(attr, enc.fe, e, a0, a1);
-    edge_enc_hidden(enc, af, a0, a1, u);
-    edge_enc_out(enc, af, u, e0);
+    edge_enc_hidden(enc, af, e, a0, a1, u);
+    edge_enc_out(enc, af, e, u, e0);
     for (int c = 0; c < n_classes; ++c) {
       float z = cls_b[c];
 #pragma unroll

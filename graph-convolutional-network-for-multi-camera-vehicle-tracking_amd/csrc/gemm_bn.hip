@@ -86,6 +86,13 @@ __global__ __launch_bounds__(256) void gemm_bn_kernel(GemmParams p, int tiles_m,
         v.y = fmaxf(fmaf(v.y, s.y, t.y), 0.f);
         v.z = fmaxf(fmaf(v.z, s.z, t.z), 0.f);
         v.w = fmaxf(fmaf(v.w, s.w, t.w), 0.f);
+        if (p.drop_in.on) {
+          const unsigned long long idx = (unsigned long long)(m0 + r) * p.K + k_base + k0 + c4 * 4;
+          v.x = drop_apply(p.drop_in, p.drop_stream, idx, v.x);
+          v.y = drop_apply(p.drop_in, p.drop_stream, idx + 1, v.y);
+          v.z = drop_apply(p.drop_in, p.drop_stream, idx + 2, v.z);
+          v.w = drop_apply(p.drop_in, p.drop_stream, idx + 3, v.w);
+        }
       }
       *reinterpret_cast<float4*>(As + r * LDK + c4 * 4) = v;
     }

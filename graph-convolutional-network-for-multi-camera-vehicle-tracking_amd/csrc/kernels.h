@@ -17,7 +17,9 @@ struct PrepParams {
 struct RoundParams {
   const int* row32; const int* col32; const float* attr;
   const float* e_prev;       // [E][4] edge state of the previous round (unused in the first round)
-  float* e_buf;              // [E][4] this round: z1 (pass A) -> e' in place (pass B) -> read by pass C
+  float* e_buf;              // [E][4] this round: z1 written by pass A
+  float* e_out;              // [E][4] e' written by pass B, read by pass C (eval: == e_buf, in place; training: kept apart)
+  Drop drop_e, drop_n; unsigned drop_stream;   // training: dropout of the edge / node update MLPs
   const float* P;            // [N][8]  Pr | Pc
   const float* Q;            // [N][32]
   const float* ue_w; const float* ue_b; const float* ue_g; const float* ue_bt; int ue_ld; int ue_eoff;
@@ -36,6 +38,7 @@ struct NodeProjParams {
   // fused first round: h = relu(bn(y_last)) computed on the fly (and stored to h0_out) instead of read from h_src
   const float* y_last; const double* y_stats; const float* y_gamma; const float* y_beta; double y_count; float* h0_out;
   int finalize_enc; EdgeEncParams enc; double e_total;   // block 0 also finalises the edge-encoder affines
+  Drop drop; unsigned drop_stream;                       // dropout on the fused h0 (training)
   const float* h_src;        // [N][32]
   const float* h0;           // [N][32] (reattach_nodes) or nullptr
   const int* deg;            // mean aggregation: scale h_src rows by 1/max(deg,1); else nullptr
@@ -64,6 +67,7 @@ struct GemmParams {
   double count;                      // BatchNorm row count (global N)
   double* stats_out;                 // f64[2*Nout], accumulated atomically
   int64_t M; int K; int Nout;
+  Drop drop_in; unsigned drop_stream;  // training: dropout applied with the input BatchNorm+ReLU
   float* slab;                       // [split_k][M][Nout] scratch for split-K partial tiles, or nullptr
   int split_k;                       // set by launch_gemm_bn
 };
@@ -81,7 +85,8 @@ void launch_node_proj(const NodeProjParams& p, hipStream_t s);
 void launch_node_stat(const NodeStatParams& p, hipStream_t s);
 // h_dst[i][k] = relu(s_k * Y[i][k] + t_k) for local rows; stats over `count` rows
 void launch_bn_relu_rows(const float* Y, int64_t ldy, int64_t rows, int dim, const double* stats, const float* gamma,
-                         const float* beta, double count, float* dst, hipStream_t s);
+                         const float* beta, double count, float* dst, Drop drop, unsigned drop_stream, int64_t row0,
+                         hipStream_t s);
 // dst = src (sum/max) or src / max(deg,1) (mean)
 void launch_h_final(const float* src, const int* deg, int mean, int64_t n_nodes, float* dst, hipStream_t s);
 

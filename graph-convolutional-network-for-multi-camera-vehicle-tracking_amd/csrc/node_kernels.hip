@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256) void node_proj_kernel(NodeProjParams p) {
       float v = 0.f;
       if (node < p.n_nodes) {
         if (p.y_last) {
-          v = fmaxf(fmaf(p.y_last[node * kH + kk], ys[kk], yt[kk]), 0.f);
+          v = drop_apply(p.drop, p.drop_stream, (unsigned long long)node * kH + kk,
+                         fmaxf(fmaf(p.y_last[node * kH + kk], ys[kk], yt[kk]), 0.f));
           p.h0_out[node * kH + kk] = v;
         } else {
           v = p.h_src[node * kH + kk];
@@ -115,7 +116,8 @@ __global__ __launch_bounds__(256) void node_stat_kernel(NodeStatParams p) {
 
 __global__ __launch_bounds__(256) void bn_relu_rows_kernel(const float* Y, int64_t ldy, int64_t rows, int dim,
                                                            const double* stats, const float* gamma, const float* beta,
-                                                           double count, float* dst) {
+                                                           double count, float* dst, Drop drop, unsigned drop_stream,
+                                                           int64_t row0) {
   const int64_t total = rows * dim;
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += nthreads) {
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void bn_relu_rows_kernel(const float* Y, int64
     const int c = (int)(i % dim);
     float s, t;
     bn_affine(stats[c], stats[dim + c], count, gamma[c], beta[c], s, t);
-    dst[i] = fmaxf(fmaf(Y[r * ldy + c], s, t), 0.f);
+    dst[i] = drop_apply(drop, drop_stream, (unsigned long long)(row0 + r) * dim + c, fmaxf(fmaf(Y[r * ldy + c], s, t), 0.f));
   }
 }
 
@@ -147,9 +149,10 @@ void launch_node_stat(const NodeStatParams& p, hipStream_t s) {
   hipLaunchKernelGGL(node_stat_kernel, dim3(cap_grid((p.n_nodes + 7) / 8)), dim3(256), 0, s, p);
 }
 void launch_bn_relu_rows(const float* Y, int64_t ldy, int64_t rows, int dim, const double* stats, const float* gamma,
-                         const float* beta, double count, float* dst, hipStream_t s) {
+                         const float* beta, double count, float* dst, Drop drop, unsigned drop_stream, int64_t row0,
+                         hipStream_t s) {
   hipLaunchKernelGGL(bn_relu_rows_kernel, dim3(cap_grid((rows * dim + 255) / 256)), dim3(256), 0, s, Y, ldy, rows, dim,
-                     stats, gamma, beta, count, dst);
+                     stats, gamma, beta, count, dst, drop, drop_stream, row0);
 }
 void launch_h_final(const float* src, const int* deg, int mean, int64_t n_nodes, float* dst, hipStream_t s) {
   hipLaunchKernelGGL(h_final_kernel, dim3(cap_grid((n_nodes * kH + 255) / 256)), dim3(256), 0, s, src, deg, mean,

@@ -1,0 +1,58 @@
+// Launch interface of the backward kernels (train_kernels.hip).
+#pragma once
+#include "kernels.h"
+
+namespace mtmc {
+
+constexpr int kBwdStrideD = 256;   // doubles per replica of the backward statistics scratch (api_internal.h: kBwdStride)
+
+struct BwdRoundParams {
+  RoundParams f;             // the forward parameters of this round (tape pointers, weights, statistics, dropout)
+  const float* g_h;          // [N][32] gradient wrt the round's aggregated node state (as consumed: mean-scaled)
+  const float* h_agg;        // [N][32] the aggregated values (max aggregation routes the gradient to the arg max)
+  const int* deg;
+  int* arg;                  // [N][32] max aggregation: edge index of the arg max per (node, channel)
+  const float* d_logits;     // [E][C] gradient of this round's logits, or nullptr
+  float* g_dz2;              // [E][32] scratch: gradient wrt the node-update pre-activation
+  float* g_Q; float* g_P;    // [N][32], [N][8] (zeroed by the host before the round)
+  float* g_e;                // [E][4] in: gradient wrt e_r from later rounds; becomes g1 (mode 0 of the edge kernel)
+  float* g_e_prev;           // [E][4] out: gradient wrt e_{r-1}
+  float* g_e0;               // [E][4] accumulated gradient wrt the encoded edges
+  double* bst;               // backward statistics scratch (zeroed by the host before each statistics pass)
+  float* gr_un_w; float* gr_un_b; float* gr_un_g; float* gr_un_bt;
+  float* gr_ue_w; float* gr_ue_b; float* gr_ue_g; float* gr_ue_bt;
+  float* gr_cls_w; float* gr_cls_b;
+};
+
+struct BwdProjParams {
+  const float* g_P; const float* g_Q;
+  const float* h_src; const float* h0; const int* deg;
+  const float* ue_w; int ue_ld; const float* un_w; int un_ld; int hn;
+  float* g_h_prev; float* g_h0; int src_is_h0;
+  float* gr_ue_w; float* gr_un_w;
+  int64_t n_nodes;
+};
+
+struct BwdEncParams {
+  EdgeEncParams enc; const float* attr; int64_t n_edges; double e_total;
+  const float* g_e0; double* bst; float* d_attr;
+  float* gr_w1; float* gr_b1; float* gr_g1; float* gr_bt1;
+  float* gr_w2; float* gr_b2; float* gr_g2; float* gr_bt2;
+};
+
+struct BnBwdParams {
+  const float* Y; float* dA; int64_t rows; int dim;
+  const double* stats_fwd; double* stats_bwd; double count;
+  const float* gamma; const float* beta; Drop drop; unsigned drop_stream;
+  float* gr_gamma; float* gr_beta; float* gr_bias;
+};
+
+void launch_bwd_node_upd(const BwdRoundParams& p, int mode, hipStream_t s);
+void launch_bwd_edge_upd(const BwdRoundParams& p, int mode, hipStream_t s);
+void launch_bwd_node_proj(const BwdProjParams& p, hipStream_t s);
+void launch_bwd_edge_enc(const BwdEncParams& p, int pass, hipStream_t s);
+void launch_bn_bwd(const BnBwdParams& p, int mode, hipStream_t s);
+void launch_transpose_pad(const float* src, int64_t rows, int cols, int64_t ld_src, float* dst, int64_t rows_pad,
+                          hipStream_t s);
+
+}  // namespace mtmc

@@ -33,6 +33,19 @@ class ForwardEngine:
         self._ws = {}
 
     # -- parameters -> mtmc_mpn_model ------------------------------------------------------------
+    def param_layers(self):
+        """(struct slot, Linear, BatchNorm or None, LayerSpec) for every layer, in mtmc_mpn_model order."""
+        m, s = self.module, self.spec
+        out = []
+        for i, layer in enumerate(s.enc_node):
+            out.append((("enc_node", i),) + _lin(m.encoder.node_mlp, layer) + (layer,))
+        for i, layer in enumerate(s.enc_edge):
+            out.append((("enc_edge", i),) + _lin(m.encoder.edge_mlp, layer) + (layer,))
+        out.append((("upd_edge", None),) + _lin(m.MPNet.edge_model.edge_mlp, s.upd_edge[0]) + (s.upd_edge[0],))
+        out.append((("upd_node", None),) + _lin(m.MPNet.node_model.node_mlp, s.upd_node[0]) + (s.upd_node[0],))
+        out.append((("cls", None),) + _lin(m.classifier.edge_mlp, s.cls_edge[0]) + (s.cls_edge[0],))
+        return out
+
     def model_struct(self, dev) -> _lib.Model:
         m, s = self.module, self.spec
         out = _lib.Model()
@@ -43,6 +56,9 @@ class ForwardEngine:
             dst.gamma = _check_param(bn.weight, dev) if bn is not None else None
             dst.beta = _check_param(bn.bias, dev) if bn is not None else None
             dst.in_dim, dst.out_dim = layer.in_dim, layer.out_dim
+        out.dropout_enc = float(s.enc_node[0].dropout_p or 0.0)
+        out.dropout_upd_edge = float(s.upd_edge[0].dropout_p or 0.0)
+        out.dropout_upd_node = float(s.upd_node[0].dropout_p or 0.0)
 
         if len(s.enc_node) > _lib.MAX_ENC_LAYERS:
             raise NotImplementedError("mtmc_mpn: node encoder deeper than 8 layers")
@@ -90,15 +106,11 @@ class ForwardEngine:
         if edge_index.dtype != torch.int64:
             raise RuntimeError("mtmc_mpn: edge_index must be int64")
 
-    def prepare(self, x, edge_index, edge_attr, training=False, n_edges_total=None, node_range=None):
-        """Validate, allocate outputs/workspace and fill the two C structs of one call."""
+    def prepare(self, x, edge_index, edge_attr, training=False, n_edges_total=None, node_range=None, tape=False,
+                seed=0):
+        """Validate, allocate outputs/workspace and fill the two C structs of one call.
+        `tape=True`: training-mode layout in a fresh workspace that the backward will read (kept by autograd)."""
         self.check_inputs(x, edge_index, edge_attr)
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.module.parameters())):
-            raise NotImplementedError(
-                "mtmc_mpn: the HIP backward pass is not built yet; call under torch.no_grad() "
-                "(inference, as main.py / inference.py:374 do)")
-        if training:
-            raise NotImplementedError("mtmc_mpn: training-mode forward (Dropout masks) is not built yet; use .eval()")
         s, dev = self.spec, x.device
         e = edge_index.shape[1]
         node_lo, node_hi = (0, x.shape[0]) if node_range is None else node_range[:2]
@@ -116,7 +128,13 @@ class ForwardEngine:
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
         model = self.model_struct(dev)
-        ws = self.workspace(model, n, e, dev, stream)
+        if tape:
+            need = self.lib.mtmc_mpn_train_workspace_bytes(C.byref(model), n, e)
+            if need == 0:
+                _lib.check(_lib.E_ARG)
+            ws = torch.empty(need + 256, dtype=torch.uint8, device=dev)
+        else:
+            ws = self.workspace(model, n, e, dev, stream)
         call = _lib.Call()
         call.x, call.x_row_stride = x.data_ptr(), x.stride(0)
         call.row = edge_index[0].data_ptr() if e > 0 else None
@@ -129,7 +147,7 @@ class ForwardEngine:
         call.logits = logits.data_ptr() if logits.numel() else ws.data_ptr()
         call.h_out = h.data_ptr()
         call.workspace, call.workspace_bytes = ws.data_ptr(), ws.numel()
-        call.training, call.flags, call.seed = 0, 0, 0
+        call.training, call.flags, call.seed = (1 if tape else 0), 0, int(seed) & 0xFFFFFFFFFFFFFFFF
         call.stream = stream
         keep = (x, edge_index, edge_attr)        # the structs hold raw pointers: keep the tensors alive
         return types.SimpleNamespace(model=model, call=call, ws=ws, logits=logits, h=h, n_out=n_out, n=n, e=e,
@@ -214,6 +232,11 @@ class ForwardEngine:
         return [prep.logits[i] for i in range(prep.n_out)], prep.h
 
     def __call__(self, x, edge_index, edge_attr, training=False) -> Tuple[List[torch.Tensor], torch.Tensor]:
+        needs_grad = torch.is_grad_enabled() and (
+            x.requires_grad or edge_attr.requires_grad or any(p.requires_grad for p in self.module.parameters()))
+        if needs_grad or training:
+            from . import autograd
+            return autograd.forward_with_tape(self, x, edge_index, edge_attr, training)
         prep = self.prepare(x, edge_index, edge_attr, training)
         with torch.cuda.device(prep.dev):
             _lib.check(self.lib.mtmc_mpn_forward(C.byref(prep.model), C.byref(prep.call)))

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MTMC_MPN_ABI_VERSION 1
+#define MTMC_MPN_ABI_VERSION 2
 
 #define MTMC_MAX_ENC_LAYERS 8   /* hidden layers of the node encoder MLP          */
 #define MTMC_NODE_DIM 32        /* H : width of the node state the kernels are built for */
@@ -78,6 +78,9 @@ typedef struct mtmc_mpn_model {
   int32_t num_class_steps;                      /* Cs                                           */
   int32_t reattach_nodes;                       /* reattach_initial_nodes                       */
   int32_t reattach_edges;                       /* reattach_initial_edges                       */
+  float dropout_enc;                            /* Dropout p of both encoder MLPs (training only) */
+  float dropout_upd_edge;                       /* ... of the edge-update MLP                     */
+  float dropout_upd_node;                       /* ... of the node-update MLP                     */
 } mtmc_mpn_model;
 
 /* One forward call.  For a single GPU: node_lo=0, node_hi=n_nodes, n_edges_total=n_edges. */
@@ -96,7 +99,9 @@ typedef struct mtmc_mpn_call {
   float* h_out;              /* out [n_nodes][32] = latent_node_feats                   */
   void* workspace;           /* >= mtmc_mpn_workspace_bytes(), 256-byte aligned         */
   size_t workspace_bytes;
-  int32_t training;          /* 0: eval (Dropout = identity).  1: not implemented yet   */
+  int32_t training;          /* 0: eval (Dropout = identity).  1: train: counter-based Dropout masks from `seed`,
+                                every round keeps its own buffers so the workspace doubles as the backward tape
+                                (size it with mtmc_mpn_train_workspace_bytes)                              */
   int32_t flags;             /* MTMC_F_*                                                */
   uint64_t seed;
   void* stream;              /* hipStream_t                                             */
@@ -155,6 +160,16 @@ size_t mtmc_mpn_workspace_bytes(const mtmc_mpn_model* model, int64_t n_nodes, in
 int32_t mtmc_mpn_workspace_layout(const mtmc_mpn_model* model, int64_t n_nodes, int64_t n_edges,
                                   mtmc_ws_layout* out);
 int32_t mtmc_mpn_forward(const mtmc_mpn_model* model, const mtmc_mpn_call* call);
+
+/* Training (reference train.py:356,424: outputs, _ = model(data); loss.backward()).
+ * Forward: mtmc_mpn_forward with call->training = 1 and a workspace of mtmc_mpn_train_workspace_bytes().
+ * Backward: the SAME model/call (same workspace, untouched since the forward) plus the incoming gradients
+ *   d_logits [n_outputs][E][C] and d_h [N][32] (either may be NULL = zero).  `grads` has the layout of the model
+ *   struct; its weight/bias/gamma/beta pointers name the buffers that RECEIVE the 34 parameter gradients
+ *   (overwritten, fp32).  d_x [N][F] / d_edge_attr [E][Fe] are written if non-NULL. */
+size_t mtmc_mpn_train_workspace_bytes(const mtmc_mpn_model* model, int64_t n_nodes, int64_t n_edges);
+int32_t mtmc_mpn_backward(const mtmc_mpn_model* model, const mtmc_mpn_call* call, const float* d_logits,
+                          const float* d_h, const mtmc_mpn_model* grads, float* d_x, float* d_edge_attr);
 int32_t mtmc_mpn_run_phase(const mtmc_mpn_model* model, const mtmc_mpn_call* call, int32_t phase, int32_t arg);
 
 /* out[dim_size, C] (fp32) <- scatter of src[E, C] by index[E] along dim 0; rows nobody writes are 0.
