@@ -193,13 +193,3 @@ extern "C" int32_t mtmc_mpn_backward(const mtmc_mpn_model* model, const mtmc_mpn
   return MTMC_OK;
 }
 
-// Development aid (not in the public header): byte offsets of tape regions for round `r` in the training layout.
-extern "C" int32_t mtmc_debug_tape_offsets(const mtmc_mpn_model* model, int64_t n, int64_t e, int32_t r, size_t* out) {
-  if (check_model(model) != MTMC_OK) return MTMC_E_ARG;
-  Layout lo;
-  make_layout(model, n, e, &lo, true);
-  if (r < 0 || r >= (int)lo.h_tr.size()) return MTMC_E_ARG;
-  out[0] = lo.P; out[1] = lo.Q; out[2] = lo.e_tr[r]; out[3] = lo.z_tr[r]; out[4] = lo.h_tr[r];
-  out[5] = lo.g_Q; out[6] = lo.g_dz2; out[7] = lo.g_h[0]; out[8] = lo.g_h[1]; out[9] = lo.row32; out[10] = lo.pub.h0_off;
-  return MTMC_OK;
-}
