@@ -226,6 +226,35 @@ def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
     return res
 
 
+def run_graph_build(device, with_cpu=True):
+    """SURVEY 8(f)-1,2: raw tracklet features -> (x, edge_index, edge_attr, labels), S02 ground-truth topology."""
+    import numpy as np
+    cams = np.repeat(np.arange(4), graphs.S02_GT_CAMS)
+    feats = torch.randn(cams.size, 2048, generator=torch.Generator().manual_seed(2))
+    labels = torch.randint(0, 145, (cams.size,), generator=torch.Generator().manual_seed(3)).numpy()
+    fg = feats.to(device)
+    for _ in range(5):
+        g = mtmc_mpn.build_graph(fg, cams, labels)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    reps = 30
+    for _ in range(reps):
+        g = mtmc_mpn.build_graph(fg, cams, labels)
+    torch.cuda.synchronize(device)
+    sec = (time.perf_counter() - t0) / reps
+    e = g.edge_index.shape[1]
+    out = {"workload": "S02 ground-truth topology from raw features (normalise, edges, labels, edge_attr)", "N": int(cams.size),
+           "E": e, "ms_per_build": sec * 1e3, "edges_per_s": e / sec,
+           "replaces": "inference.py:402-456 (16 KB of 2048-d gathers per edge -> one Gram matrix + 8 B/edge)"}
+    if with_cpu:
+        from oracle import graph_oracle
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        t0 = time.perf_counter()
+        graph_oracle.build(feats, cams, labels)
+        out["cpu_oracle_ms"] = (time.perf_counter() - t0) * 1e3
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -260,6 +289,7 @@ def main():
         line["stress"] = st
         # the multi-GPU workload (config 5) on this one GPU: the N=1 point of the strong-scaling curve
         line["scale_base"] = run_single("cfg5", device, 5, 2, with_cpu=False, phase_iters=2)
+        line["graph_build"] = run_graph_build(device, with_cpu=not args.no_cpu)
     print(json.dumps(line))
 
 

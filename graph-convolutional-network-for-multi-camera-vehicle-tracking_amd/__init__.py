@@ -8,8 +8,9 @@ Public surface = the reference's interface for the hot path (reference models/mp
 `scatter_add / scatter_mean / scatter_max` functional surface of the third-party op it used.
 """
 from .config import DEFAULT_ARCH, DEFAULT_GRAPH_NET_PARAMS, default_params  # noqa: F401
+from .graph_build import build_graph  # noqa: F401
 from .modules import (MLP, EdgeModel, MetaLayer, MLPGraphIndependent, MOTMPNet,  # noqa: F401
                       NodeModel)
 
 __all__ = ["MOTMPNet", "MetaLayer", "EdgeModel", "NodeModel", "MLPGraphIndependent", "MLP",
-           "DEFAULT_GRAPH_NET_PARAMS", "DEFAULT_ARCH", "default_params"]
+           "DEFAULT_GRAPH_NET_PARAMS", "DEFAULT_ARCH", "default_params", "build_graph"]

@@ -186,6 +186,22 @@ int32_t mtmc_scatter_max(const float* src, const int64_t* index, int64_t n_src, 
 int32_t mtmc_mlp_layer_forward(const mtmc_layer* layer, const float* x, int64_t x_row_stride, int64_t rows,
                                float* y, double* stats_scratch, void* stream);
 
+/* ---- graph construction (SURVEY.md 8(f)-1,2; replaces reference inference.py:402-456 / train.py:316-342) ----
+ * feats [N][F] raw per-tracklet features -> x_out [N][F] (column-normalised like F.normalize(dim=0) if l2norm),
+ * edge_index_out [E][2] int64 (row, col) in the reference's order (per camera, ascending: nodes of the camera x nodes
+ * outside it; its transpose view is the [2,E] tensor the callers pass on), edge_attr_out [E][2] =
+ * [pairwise_distance, 1 - cosine_similarity], edge_labels_out [E] (1.0 iff node_labels match; NULL to skip).
+ * The camera structure comes as small device arrays the host derives from the camera ids:
+ *   in_list/in_off[n_cams+1]: nodes of camera c;  out_list/out_off[n_cams+1]: nodes not in c (ascending);
+ *   block_off[n_cams+1]: first edge of camera c's block, block_off[n_cams] = E.
+ * Uses one N x N Gram matrix on the matrix cores instead of per-edge 2048-d gathers; N <= 46000. */
+size_t mtmc_graph_workspace_bytes(int64_t n_nodes, int32_t feat_dim);
+int32_t mtmc_build_graph(const float* feats, int64_t feat_row_stride, int64_t n_nodes, int32_t feat_dim, int32_t l2norm,
+                         const int32_t* in_list, const int32_t* in_off, const int32_t* out_list, const int64_t* out_off,
+                         const int64_t* block_off, int32_t n_cams, int64_t n_edges, const int64_t* node_labels,
+                         float* x_out, int64_t* edge_index_out, float* edge_attr_out, float* edge_labels_out,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
