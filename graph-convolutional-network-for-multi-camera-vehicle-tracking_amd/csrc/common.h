@@ -35,10 +35,37 @@ constexpr int kRoundBlock = kRoundZ2Off + kStatRep * kZ2Stride;   // doubles per
 
 __host__ __device__ __forceinline__ constexpr int tri(int n, int i, int j) { return i * n - i * (i - 1) / 2 + (j - i); }
 
+// Wave-wide sum on the DPP data path (no LDS round trips): inclusive scan inside each row of 16 lanes
+// (row_shr 1,2,4,8), then row_bcast:15 / row_bcast:31 carry the row totals up; lane 63 ends with the total.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+  return v + __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
-  return v;   // lane 0 holds the total
+  v = dpp_add_f64<0x111, 0xf>(v);   // row_shr:1
+  v = dpp_add_f64<0x112, 0xf>(v);   // row_shr:2
+  v = dpp_add_f64<0x114, 0xf>(v);   // row_shr:4
+  v = dpp_add_f64<0x118, 0xf>(v);   // row_shr:8
+  v = dpp_add_f64<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v = dpp_add_f64<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+  return v;                          // lane 63 holds the total
+}
+constexpr int kWaveSumLane = 63;
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_f32(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {   // total in lane 63
+  v = dpp_add_f32<0x111, 0xf>(v);
+  v = dpp_add_f32<0x112, 0xf>(v);
+  v = dpp_add_f32<0x114, 0xf>(v);
+  v = dpp_add_f32<0x118, 0xf>(v);
+  v = dpp_add_f32<0x142, 0xa>(v);
+  v = dpp_add_f32<0x143, 0xc>(v);
+  return v;
 }
 
 // dst[i] = sum over replicas of src[r*stride + i], i < n  (cooperative; caller synchronises afterwards)
@@ -60,7 +87,7 @@ __device__ __forceinline__ void block_atomic_add(const double (&v)[NV], double* 
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     double s = wave_sum(v[i]);
-    if (lane == 0) smem[wid * NV + i] = s;
+    if (lane == kWaveSumLane) smem[wid * NV + i] = s;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < NV; i += blockDim.x) {

@@ -224,8 +224,20 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
 #pragma unroll
         for (int b = a; b < 4; ++b) acc[4 + tri(4, a, b)] += (double)v[a] * v[b];
       }
-      // per-node segment sums S[row] += e': segmented inclusive scan over the wave (any row order),
-      // then one fp64 atomic per run and channel
+      // per-node segment sums S[row] += e'.  Common case on row-sorted lists: the whole wave sits in one row ->
+      // one DPP wave sum per channel and 4 atomics.  Otherwise a segmented inclusive scan over the wave (any row
+      // order), then one fp64 atomic per run and channel.
+      const int r0 = __builtin_amdgcn_readfirstlane(r);
+      if (__all(r == r0) && r0 >= 0) {
+        float t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = wave_sum_f32(v[k]);
+        if (lane == kWaveSumLane) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) unsafeAtomicAdd(p.seg + (int64_t)r0 * 4 + k, (double)t[k]);
+        }
+        continue;
+      }
       const int prev = __shfl_up(r, 1, 64);
       int flag = (lane == 0 || prev != r) ? 1 : 0;
       const int next_head = __shfl_down(flag, 1, 64);

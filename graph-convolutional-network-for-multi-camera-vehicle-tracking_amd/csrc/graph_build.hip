@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void gb_normalize_kernel(const float* x, int64
   }
   sq = wave_sum(sq);
   sm = wave_sum(sm);
-  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = sq; red[4 + (threadIdx.x >> 6)] = sm; }
+  if ((threadIdx.x & 63) == kWaveSumLane) { red[threadIdx.x >> 6] = sq; red[4 + (threadIdx.x >> 6)] = sm; }
   __syncthreads();
   if (threadIdx.x == 0) {
     row_sq[r] = (float)(red[0] + red[1] + red[2] + red[3]);

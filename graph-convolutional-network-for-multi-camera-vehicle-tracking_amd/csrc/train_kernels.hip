@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void bwd_edge_upd_kernel(BwdRoundParams p) {
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const double s = wave_sum(acc[i]);
-    if (lane == 0) red[wid * 64 + i] = s;
+    if (lane == kWaveSumLane) red[wid * 64 + i] = s;
   }
   __syncthreads();
   if (threadIdx.x < NV) {
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void bwd_edge_enc_kernel(BwdEncParams p) {
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const double s = wave_sum(acc[i]);
-    if (lane == 0) red[wid * 64 + i] = s;
+    if (lane == kWaveSumLane) red[wid * 64 + i] = s;
   }
   __syncthreads();
   if (threadIdx.x < NV) {
