@@ -52,7 +52,7 @@ class WsLayout(C.Structure):
 # statistics blocks (include/mtmc_mpn.h): replicas x stride doubles each
 STAT_REPLICAS, ATTR_STRIDE, ENC2_STRIDE, Z1_STRIDE, M_STRIDE, Z2_STRIDE = 16, 16, 16, 16, 16, 64
 ROUND_BLOCK = STAT_REPLICAS * (Z1_STRIDE + M_STRIDE + Z2_STRIDE)
-F_GLOBAL_DEG, F_FORK = 4, 2
+F_DETERMINISTIC, F_GLOBAL_DEG, F_FORK = 1, 4, 2
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmtmc_mpn.so")
 EXPORTS = ["mtmc_mpn_abi_version", "mtmc_mpn_last_error", "mtmc_mpn_workspace_bytes", "mtmc_mpn_workspace_layout",

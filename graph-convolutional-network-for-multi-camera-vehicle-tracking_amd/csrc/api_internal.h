@@ -29,7 +29,7 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 struct Layout {
   mtmc_ws_layout pub;
-  size_t row32, col32, e_buf[2], P, Q, slab, enc_aff;
+  size_t row32, col32, e_buf[2], P, Q, slab, enc_aff, row_start, carry;
   size_t Y[MTMC_MAX_ENC_LAYERS];
   size_t stat_enc_layer[MTMC_MAX_ENC_LAYERS];
   // training: every round keeps its own buffers (the workspace is the backward tape) + backward scratch
@@ -93,6 +93,8 @@ inline void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* l
   lo->pub.h_acc_off[0] = take((size_t)N * 32 * sizeof(float));
   lo->pub.h_acc_off[1] = take((size_t)N * 32 * sizeof(float));
   lo->enc_aff = take(16 * sizeof(float));
+  lo->row_start = take((size_t)N * sizeof(int32_t));
+  lo->carry = take((size_t)((E + 31) / 32) * 2 * 32 * sizeof(float));
   lo->P = take((size_t)N * 8 * sizeof(float));
   lo->Q = take((size_t)N * 32 * sizeof(float));
   lo->row32 = take((size_t)E * sizeof(int32_t));
@@ -238,6 +240,9 @@ inline mtmc::RoundParams round_params(const Ctx& x, int r) {
   p.logits = step >= first_cls ? x.c->logits + (size_t)(step - first_cls) * x.c->n_edges * m->cls.out_dim : nullptr;
   p.n_edges = x.c->n_edges; p.e_total = (double)x.c->n_edges_total;
   p.first_round = r == 0; p.reattach_edges = m->reattach_edges; p.agg = m->agg;
+  p.det = (x.c->flags & MTMC_F_DETERMINISTIC) ? 1 : 0; p.flags = x.at<int>(x.lo.pub.flags_off);
+  p.deg = x.at<int>(x.lo.pub.deg_off); p.row_start = x.at<int>(x.lo.row_start); p.carry = x.at<float>(x.lo.carry);
+  p.n_nodes = x.c->n_nodes;
   p.enc = enc_params(x);
   return p;
 }
@@ -265,6 +270,7 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
         p.n_edges = c->n_edges; p.n_nodes = c->n_nodes;
         p.row32 = x.at<int>(x.lo.row32); p.col32 = x.at<int>(x.lo.col32); p.deg = x.at<int>(x.lo.pub.deg_off);
         p.flags = x.at<int>(x.lo.pub.flags_off); p.stat_attr = x.at<double>(x.lo.pub.stat_attr_off);
+        p.row_start = x.at<int>(x.lo.row_start);
         mtmc::launch_prep(p, s);
       }
       break;

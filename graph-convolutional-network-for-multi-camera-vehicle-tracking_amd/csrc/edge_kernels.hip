@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepParams p) {
     int prev = __shfl_up(r, 1, 64);
     if (lane == 0) prev = (active && e > 0) ? (int)p.row[(e - 1) * p.idx_stride] : r;
     if (active && prev > r) p.flags[0] = 1;               // rows not globally non-decreasing
+    if (active && (e == 0 || prev != r)) p.row_start[r] = (int)e;   // first edge of the row (meaningful when sorted)
     // out-degree: one atomic per run of equal rows inside the wave
     const bool head = active && (lane == 0 || prev != r);
     const unsigned long long heads = __ballot(head);
@@ -268,12 +269,47 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
 // ------------------------------------------------------------------------------------------------
 constexpr int kTileC = 256;
 
+// Order-independent aggregation for row-sorted lists (MTMC_F_DETERMINISTIC): a 32-edge chunk's first run goes to
+// carry[chunk][0], its last run (if different) to carry[chunk][1], runs strictly inside the chunk are complete rows
+// and are stored directly; agg_fixup_kernel then adds each row's pieces in chunk order.  slot: 0 / 1 / -1 (inside).
+__device__ __forceinline__ void flush_run(const RoundParams& p, bool det, int64_t chunk, int slot, int node, int k,
+                                          float acc);
+
 __device__ __forceinline__ void flush_node(const RoundParams& p, int node, int k, float acc) {
   float* dst = p.h_acc + (int64_t)node * kH + k;
   if (p.agg == 2) {
     atomicMax(reinterpret_cast<int*>(dst), __float_as_int(acc));   // values are >= 0: int order == float order
   } else {
     unsafeAtomicAdd(dst, acc);
+  }
+}
+
+__device__ __forceinline__ void flush_run(const RoundParams& p, bool det, int64_t chunk, int slot, int node, int k,
+                                          float acc) {
+  if (!det) { flush_node(p, node, k, acc); return; }
+  if (slot < 0) p.h_acc[(int64_t)node * kH + k] = acc;
+  else p.carry[(chunk * 2 + slot) * kH + k] = acc;
+}
+
+__global__ __launch_bounds__(256) void agg_fixup_kernel(RoundParams p) {
+  if (p.flags[0] != 0) return;                       // unsorted rows: pass C used atomics, nothing to add up
+  const int k = threadIdx.x & 31;
+  const int64_t stride = (int64_t)gridDim.x * 8;
+  for (int64_t i = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5); i < p.n_nodes; i += stride) {
+    const int d = p.deg[i];
+    if (d == 0) continue;
+    const int64_t s = p.row_start[i], t = s + d;
+    const int64_t cs = s >> 5, ce = (t - 1) >> 5;
+    float v;
+    if (cs == ce) {
+      if ((s & 31) == 0) v = p.carry[(cs * 2 + 0) * kH + k];
+      else if ((t & 31) == 0 || t == p.n_edges) v = p.carry[(cs * 2 + 1) * kH + k];
+      else continue;                                 // strictly inside its chunk: already stored
+    } else {
+      v = p.carry[(cs * 2 + ((s & 31) == 0 ? 0 : 1)) * kH + k];
+      for (int64_t c = cs + 1; c <= ce; ++c) v += p.carry[(c * 2 + 0) * kH + k];
+    }
+    p.h_acc[i * kH + k] = v;
   }
 }
 
@@ -297,6 +333,7 @@ __global__ __launch_bounds__(256) void pass_c_kernel(RoundParams p) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) a4[j] = sk * p.un_w[k * p.un_ld + p.un_eoff + j];
   const float cb = fmaf(sk, p.un_b[k], tk);
+  const bool det = p.det && p.agg != 2 && p.flags[0] == 0;      // max is order-independent as it is
 
   const int64_t n_tiles = (p.n_edges + kTileC - 1) / kTileC;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -322,13 +359,15 @@ __global__ __launch_bounds__(256) void pass_c_kernel(RoundParams p) {
     tile_e[threadIdx.x] = ev;
     __syncthreads();
     const int n_here = (int)min((int64_t)32, p.n_edges - (base + hw * 32));   // may be <= 0
+    const int64_t chunk = (base >> 5) + hw;
     int cur = -1;
+    bool first = true;
     float acc = 0.f, c0 = 0.f;
     for (int j = 0; j < n_here; ++j) {
       const int r = tile_row[hw * 32 + j];
       const float4 v = tile_e[hw * 32 + j];
       if (r != cur) {
-        if (cur >= 0) flush_node(p, cur, k, acc);
+        if (cur >= 0) { flush_run(p, det, chunk, first ? 0 : -1, cur, k, acc); first = false; }
         cur = r;
         acc = 0.f;
         c0 = fmaf(sk, p.Q[(int64_t)r * kH + k], cb);
@@ -337,7 +376,7 @@ __global__ __launch_bounds__(256) void pass_c_kernel(RoundParams p) {
       m = drop_apply(p.drop_n, p.drop_stream + 1, (unsigned long long)(base + hw * 32 + j) * kH + k, m);
       acc = (p.agg == 2) ? fmaxf(acc, m) : acc + m;
     }
-    if (cur >= 0) flush_node(p, cur, k, acc);
+    if (cur >= 0) flush_run(p, det, chunk, first ? 0 : 1, cur, k, acc);
     __syncthreads();
   }
 }
@@ -387,6 +426,10 @@ void launch_pass_b(const RoundParams& p, hipStream_t s) {
 }
 void launch_pass_c(const RoundParams& p, hipStream_t s) {
   hipLaunchKernelGGL(pass_c_kernel, dim3(edge_grid(p.n_edges, kTileC)), dim3(256), 0, s, p);
+  if (p.det && p.agg != 2) {
+    const int64_t blocks = (p.n_nodes + 7) / 8;
+    hipLaunchKernelGGL(agg_fixup_kernel, dim3((int)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks))), dim3(256), 0, s, p);
+  }
 }
 void launch_classify_e0(const EdgeEncParams& enc, const float* attr, int64_t n_edges, double e_total,
                         const float* cls_w, const float* cls_b, int n_classes, float* logits, hipStream_t s) {

@@ -9,7 +9,7 @@ struct PrepParams {
   const int64_t* row; const int64_t* col; int64_t idx_stride;
   const float* attr; int fe;
   int64_t n_edges; int64_t n_nodes;
-  int* row32; int* col32; int* deg; int* flags;
+  int* row32; int* col32; int* deg; int* flags; int* row_start;
   double* stat_attr;
 };
 
@@ -31,6 +31,7 @@ struct RoundParams {
   float* logits;             // this round's [E][C] output or nullptr
   int64_t n_edges; double e_total;
   int first_round; int reattach_edges; int agg;
+  int det; const int* flags; const int* deg; const int* row_start; float* carry; int64_t n_nodes;   // deterministic sums
   EdgeEncParams enc;
 };
 

@@ -84,7 +84,7 @@ class ShardedForward:
         n = node_range[2]
         mean = spec.agg == "mean"
         if mean:
-            be.set_flags(prep, _lib.F_GLOBAL_DEG)
+            be.set_flags(prep, _lib.F_GLOBAL_DEG)        # (replaces the flags: the sharded path sums with atomics)
         rows = even_ranges(n, world)
         if tuple(rows[rank]) != tuple(node_range[:2]):
             raise ValueError(f"rank {rank} must encode node rows {rows[rank]} (even_ranges), got {node_range[:2]}")

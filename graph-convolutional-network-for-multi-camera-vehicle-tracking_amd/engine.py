@@ -147,7 +147,8 @@ class ForwardEngine:
         call.logits = logits.data_ptr() if logits.numel() else ws.data_ptr()
         call.h_out = h.data_ptr()
         call.workspace, call.workspace_bytes = ws.data_ptr(), ws.numel()
-        call.training, call.flags, call.seed = (1 if tape else 0), 0, int(seed) & 0xFFFFFFFFFFFFFFFF
+        call.training, call.seed = (1 if tape else 0), int(seed) & 0xFFFFFFFFFFFFFFFF
+        call.flags = _lib.F_DETERMINISTIC if getattr(self.module, "deterministic", False) else 0
         call.stream = stream
         keep = (x, edge_index, edge_attr)        # the structs hold raw pointers: keep the tensors alive
         return types.SimpleNamespace(model=model, call=call, ws=ws, logits=logits, h=h, n_out=n_out, n=n, e=e,

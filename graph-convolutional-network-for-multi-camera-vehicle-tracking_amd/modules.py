@@ -121,6 +121,7 @@ class MOTMPNet(nn.Module):
         self.num_enc_steps = s.num_enc_steps
         self.num_class_steps = s.num_class_steps
         self.check_indices = False          # True: synchronise and raise IndexError on out-of-range edge_index
+        self.deterministic = False          # True: order-independent sum/mean aggregation on row-sorted edge lists
         self._engine = None
 
     # -- the hot path -------------------------------------------------------------------

@@ -107,7 +107,8 @@ typedef struct mtmc_mpn_call {
   void* stream;              /* hipStream_t                                             */
 } mtmc_mpn_call;
 
-#define MTMC_F_DETERMINISTIC 1   /* reserved: order-independent segment sums            */
+#define MTMC_F_DETERMINISTIC 1   /* row-sorted edge lists: sum/mean aggregation through per-chunk partials added in
+                                    a fixed order instead of float atomics (bitwise run-to-run reproducible h) */
 #define MTMC_F_GLOBAL_DEG 4      /* mean aggregation divides by workspace deg_global (multi-GPU) instead of deg */
 #define MTMC_F_FORK 2            /* run the edge branch (prep, edge-encoder moments) on an internal side stream
                                     beside the node-encoder GEMMs, joined by events (default: one stream) */

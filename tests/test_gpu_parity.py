@@ -283,3 +283,23 @@ def test_sharded_path_world_one_equals_monolithic():
         assert (h - href).abs().max().item() <= 1e-6 * href.abs().max().item()
     finally:
         dist.destroy_process_group()
+
+
+def test_deterministic_mode_is_bitwise_repeatable_and_correct():
+    """MTMC_F_DETERMINISTIC: per-chunk partial sums added in a fixed order instead of float atomics."""
+    from oracle import mpn_oracle
+    for name in ("g4_s02_L3", "g5_mean", "g8_train_topology_L3", "g2_random_L3_C3"):   # sorted, mean, block-sorted, unsorted
+        c = Case(name)
+        m, d = c.model(), c.graph()
+        m = m.cuda().eval()
+        m.deterministic = True
+        g = to_gpu(d)
+        with torch.no_grad():
+            o1, h1 = m(g)
+            o2, h2 = m(g)
+        for i in range(c.meta["n_out"]):
+            assert (o1["classified_edges"][i].cpu()[c.sub_idx] - c.logits(i)).abs().max().item() <= LOGIT_TOL, name
+        scale = max(1.0, c.h(f64=True).abs().max().item())
+        assert (h1.cpu().double() - c.h(f64=True)).abs().max().item() <= 1e-4 * scale
+        if name == "g4_s02_L3":                # globally row-sorted: the fixed-order path is taken
+            assert torch.equal(h1, h2)
