@@ -181,6 +181,7 @@ def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
     params = mtmc_mpn.default_params(num_enc_steps=L, num_class_steps=cs)
     torch.manual_seed(0)
     model = mtmc_mpn.MOTMPNet(copy.deepcopy(params), None, ARCH).to(device).eval()
+    model.deterministic = bool(os.environ.get("MTMC_DETERMINISTIC"))
     data = make_workload(name, device)
     n, e = data.x.shape[0], data.edge_index.shape[1]
     sec = time_forward(model, data, steps, warmup)
