@@ -9,13 +9,15 @@
 // so every [N, d] activation is written once and read once.
 //
 // Arithmetic: exact fp32 on v_mfma_f32_32x32x2_f32 (bit-for-bit a k-ordered fmaf chain; there is no
-// reduced-precision f32 path on gfx950 and BatchNorm amplifies input error).
+// reduced-precision f32 path on gfx950 and BatchNorm amplifies input error).  Large problems
+// take gemm_bn_bf16x6_kernel below instead: the same layer as six bf16 products per fp32 product, at fp32 accuracy.
 // Tiling: 256 threads = 2x2 waves, each wave TM x TN MFMA tiles of 32x32, BK = 32.  A and W tiles are both
 // k-contiguous in HBM and in LDS (rows padded to 36 floats => conflict-free ds_read_b128); a lane's
 // 16-byte read feeds four consecutive MFMAs (lane half h supplies k = 8*kk + 4*h + j in step j, for A and
 // W alike, so the k-permutation cancels).  Register-staged double buffering: the next k-tile's global loads
 // are in flight while the current one is multiplied.
 #include "kernels.h"
+#include <stdlib.h>
 
 namespace mtmc {
 
@@ -192,6 +194,218 @@ __global__ __launch_bounds__(256) void gemm_bn_kernel(GemmParams p, int tiles_m,
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same layer on the bf16 matrix cores at fp32 accuracy: every fp32 operand is split into three bf16 pieces
+// (x = x1 + x2 + x3, 24 mantissa bits in all) and the six products whose weight is >= 2^-16 are accumulated in fp32:
+//     a.w ~= a1w1 + a1w2 + a2w1 + a2w2 + a1w3 + a3w1            (dropped terms <= 2^-24 |a||w|, i.e. fp32 rounding)
+// Six v_mfma_f32_32x32x16_bf16 (32 cycles each, K=16) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each) per 16-deep
+// step: 2.7x fewer matrix cycles.  Measured end-to-end error at the logits: 1.4e-6 (fp32 MFMA: 3.7e-6; a 3-product
+// split would be 5.5e-5), DESIGN.md 3.1.  The split happens once per element while the tile is staged into LDS.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(float x, __bf16& b1, __bf16& b2, __bf16& b3) {
+  b1 = (__bf16)x;
+  float r = x - (float)b1;
+  b2 = (__bf16)r;
+  r -= (float)b2;
+  b3 = (__bf16)r;
+}
+
+template <int TM, int TN, int BK>
+__global__ __launch_bounds__(256) void gemm_bn_bf16x6_kernel(GemmParams p, int tiles_m, int tiles_n) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int LDB = BK + 8;                         // 80 / 144-byte rows: conflict-free 16-byte fragment reads
+  constexpr int C4 = BK / 4, A4 = BM * C4 / 256, B4 = BN * C4 / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16* As = reinterpret_cast<__bf16*>(smem);       // [3][BM][LDB]
+  __bf16* Bs = As + 3 * BM * LDB;                     // [3][BN][LDB]
+  const int kc = p.K / p.split_k;
+  const int k_base = blockIdx.y * kc;
+  float* s_in = reinterpret_cast<float*>(Bs + 3 * BN * LDB);
+  float* t_in = s_in + kc;
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tm_idx = (slot / tiles_n) * 8 + xcd, tn_idx = slot % tiles_n;
+  if (tm_idx >= tiles_m) return;
+  const int64_t m0 = (int64_t)tm_idx * BM;
+  const int n0 = tn_idx * BN;
+  const bool act = p.stats_in != nullptr;
+  if (act) {
+    for (int kk = threadIdx.x; kk < kc; kk += 256)
+      bn_affine(p.stats_in[k_base + kk], p.stats_in[p.K + k_base + kk], p.count, p.gamma_in[k_base + kk],
+                p.beta_in[k_base + kk], s_in[kk], t_in[kk]);
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+
+  float4 ra[A4], rb[B4];
+  auto load_tiles = [&](int kt) {
+    const int k0 = k_base + kt * BK;
+#pragma unroll
+    for (int i = 0; i < A4; ++i) {
+      const int f = threadIdx.x + i * 256, r = f / C4, c4 = f % C4;
+      const int64_t row = m0 + r;
+      ra[i] = row < p.M ? *reinterpret_cast<const float4*>(p.A + row * p.lda + k0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < B4; ++i) {
+      const int f = threadIdx.x + i * 256, r = f / C4, c4 = f % C4;
+      const int n = n0 + r;
+      rb[i] = n < p.Nout ? *reinterpret_cast<const float4*>(p.W + (int64_t)n * p.K + k0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto put = [&](__bf16* base, int rows, int r, int c4, float4 v) {
+    bf16x4 q1, q2, q3;
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { __bf16 a, b, c; split3(x[j], a, b, c); q1[j] = a; q2[j] = b; q3[j] = c; }
+    *reinterpret_cast<bf16x4*>(base + (0 * rows + r) * LDB + c4 * 4) = q1;
+    *reinterpret_cast<bf16x4*>(base + (1 * rows + r) * LDB + c4 * 4) = q2;
+    *reinterpret_cast<bf16x4*>(base + (2 * rows + r) * LDB + c4 * 4) = q3;
+  };
+  auto store_tiles = [&](int kt) {
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < A4; ++i) {
+      const int f = threadIdx.x + i * 256, r = f / C4, c4 = f % C4;
+      float4 v = ra[i];
+      if (act) {
+        const float4 s = *reinterpret_cast<const float4*>(s_in + k0 + c4 * 4);
+        const float4 t = *reinterpret_cast<const float4*>(t_in + k0 + c4 * 4);
+        v.x = fmaxf(fmaf(v.x, s.x, t.x), 0.f);
+        v.y = fmaxf(fmaf(v.y, s.y, t.y), 0.f);
+        v.z = fmaxf(fmaf(v.z, s.z, t.z), 0.f);
+        v.w = fmaxf(fmaf(v.w, s.w, t.w), 0.f);
+        if (p.drop_in.on) {
+          const unsigned long long idx = (unsigned long long)(m0 + r) * p.K + k_base + k0 + c4 * 4;
+          v.x = drop_apply(p.drop_in, p.drop_stream, idx, v.x);
+          v.y = drop_apply(p.drop_in, p.drop_stream, idx + 1, v.y);
+          v.z = drop_apply(p.drop_in, p.drop_stream, idx + 2, v.z);
+          v.w = drop_apply(p.drop_in, p.drop_stream, idx + 3, v.w);
+        }
+      }
+      put(As, BM, r, c4, v);
+    }
+#pragma unroll
+    for (int i = 0; i < B4; ++i) {
+      const int f = threadIdx.x + i * 256, r = f / C4, c4 = f % C4;
+      put(Bs, BN, r, c4, rb[i]);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = kc / BK;
+  load_tiles(0);
+  const int a_off = (wm * TM * 32 + (lane & 31)) * LDB + (lane >> 5) * 8;
+  const int b_off = (wn * TN * 32 + (lane & 31)) * LDB + (lane >> 5) * 8;
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    store_tiles(kt);
+    __syncthreads();
+    if (kt + 1 < nk) load_tiles(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 a[TM][3], b[TN][3];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(As + q * BM * LDB + a_off + i * 32 * LDB + ks * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(Bs + q * BN * LDB + b_off + j * 32 * LDB + ks * 16);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          // smallest terms first so they are not absorbed one by one into a large accumulator
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+
+  if (p.split_k > 1) {
+    float* slab = p.slab + (size_t)blockIdx.y * p.M * p.Nout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row < p.M && col < p.Nout) slab[row * p.Nout + col] = acc[i][j][r];
+        }
+    }
+    return;
+  }
+  __syncthreads();
+  double* colred = reinterpret_cast<double*>(smem);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int cl = wn * TN * 32 + j * 32 + (lane & 31);
+    const int col = n0 + cl;
+    const float bias = col < p.Nout ? p.bias[col] : 0.f;
+    double cs = 0, cq = 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < p.M && col < p.Nout) {
+          const float y = acc[i][j][r] + bias;
+          p.Y[row * p.ldy + col] = y;
+          cs += y;
+          cq += (double)y * y;
+        }
+      }
+    }
+    cs += __shfl_xor(cs, 32, 64);
+    cq += __shfl_xor(cq, 32, 64);
+    if (lane < 32) {
+      colred[(wm * 2 + 0) * BN + cl] = cs;
+      colred[(wm * 2 + 1) * BN + cl] = cq;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * BN; i += 256) {
+    const int which = i / BN, cl = i % BN, col = n0 + cl;
+    if (col < p.Nout && p.stats_out)
+      unsafeAtomicAdd(p.stats_out + which * p.Nout + col, colred[(0 * 2 + which) * BN + cl] + colred[(1 * 2 + which) * BN + cl]);
+  }
+}
+
+template <int TM, int TN, int BK>
+static void launch_bf16x6(const GemmParams& p, hipStream_t s) {
+  constexpr int BM = 64 * TM, BN = 64 * TN, LDB = BK + 8;
+  const int tiles_m = (int)((p.M + BM - 1) / BM), tiles_n = (p.Nout + BN - 1) / BN;
+  const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
+  size_t lds = (size_t)3 * (BM + BN) * LDB * 2 + (size_t)2 * (p.K / p.split_k) * sizeof(float);
+  const size_t epi = (size_t)4 * BN * sizeof(double);
+  if (lds < epi) lds = epi;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bn_bf16x6_kernel<TM, TN, BK>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_bn_bf16x6_kernel<TM, TN, BK>), dim3(grid, p.split_k), dim3(256), lds, s, p, tiles_m, tiles_n);
+}
+
 // Second half of a split-K layer: Y = bias + sum of the K-slices' slabs (fixed order => reproducible),
 // and the fp64 column statistics of Y.  Block = 64 columns x kCombRows rows; thread = one column, every 4th row;
 // all of a row's slice loads are issued together (they are independent; only the additions are ordered).
@@ -306,7 +520,9 @@ int launch_gemm_bn(const GemmParams& p, hipStream_t s, int which) {
   const int cfg = gemm_plan(p.M, p.K, p.Nout, &sk);
   q.split_k = (p.slab != nullptr) ? sk : 1;
   if (which & 1) {
-    if (cfg == 2) launch_cfg<2, 2, 32>(q, s);
+    static const bool fp32_only = getenv("MTMC_GEMM_FP32") != nullptr;
+    if (cfg == 2 && !fp32_only) launch_bf16x6<2, 2, 32>(q, s);
+    else if (cfg == 2) launch_cfg<2, 2, 32>(q, s);
     else if ((p.K / q.split_k) % 64 == 0) launch_cfg<1, 1, 64>(q, s);
     else launch_cfg<1, 1, 32>(q, s);
   }
