@@ -271,6 +271,43 @@ def run_graph_build(device, with_cpu=True):
     return out
 
 
+def run_training_step(device):
+    """BASELINE config 3 shape: 100 identities of the training scenes (N~430, E~173k), L=3, Cs=3, forward with
+    Dropout + cross-entropy over the classified steps + backward + SGD step (lr 0.01, momentum 0.9, wd 1e-4)."""
+    import json as _json
+    with open(os.path.join(ROOT, "tests", "golden", "train_tracklets.json")) as f:
+        tr = _json.load(f)["tracklets"]
+    d = graphs.training_graph(tr, 100, 2048, 3)
+    params = mtmc_mpn.default_params(num_enc_steps=3, num_class_steps=3)
+    torch.manual_seed(0)
+    model = mtmc_mpn.MOTMPNet(copy.deepcopy(params), None, ARCH).to(device).train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    ei = d.edge_index.t().contiguous().to(device).t()
+    data = types.SimpleNamespace(x=d.x.to(device), edge_index=ei, edge_attr=d.edge_attr.to(device))
+    labels = d.edge_labels.long().to(device)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out, _ = model(data)
+        loss = sum(torch.nn.functional.cross_entropy(o, labels) for o in out["classified_edges"])
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    reps = 30
+    for _ in range(reps):
+        loss = step()
+    torch.cuda.synchronize(device)
+    sec = (time.perf_counter() - t0) / reps
+    e = data.edge_index.shape[1]
+    return {"workload": "training-scene topology, 100 identities: forward(Dropout)+CE+backward+SGD, L=3 Cs=3",
+            "N": int(data.x.shape[0]), "E": int(e), "ms_per_step": sec * 1e3, "edges_per_s": e / sec,
+            "final_loss": float(loss)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -306,6 +343,7 @@ def main():
         # the multi-GPU workload (config 5) on this one GPU: the N=1 point of the strong-scaling curve
         line["scale_base"] = run_single("cfg5", device, 5, 2, with_cpu=False, phase_iters=2)
         line["graph_build"] = run_graph_build(device, with_cpu=not args.no_cpu)
+        line["training_step"] = run_training_step(device)
     print(json.dumps(line))
 
 

@@ -1,0 +1,41 @@
+"""CPU test: the built shared library exports every symbol include/mtmc_mpn.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mtmc_mpn import _lib
+    header = open(os.path.join(ROOT, "include", "mtmc_mpn.h")).read()
+    declared = set(re.findall(r"\b(mtmc_[a-z_0-9]+)\s*\(", header))
+    declared -= {"mtmc_scatter_"}                       # prose in a comment
+    assert {"mtmc_mpn_forward", "mtmc_mpn_backward", "mtmc_mpn_run_phase", "mtmc_build_graph",
+            "mtmc_scatter_add", "mtmc_scatter_mean", "mtmc_scatter_max", "mtmc_mlp_layer_forward"} <= declared
+    assert os.path.exists(_lib.LIB_PATH), "run `python -m mtmc_mpn.build` (or __graft_entry__.build()) first"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert set(_lib.EXPORTS) <= declared
+    lib.mtmc_mpn_abi_version.restype = ctypes.c_int32
+    assert lib.mtmc_mpn_abi_version() == 2
+
+
+def test_workspace_sizing_needs_no_gpu():
+    import mtmc_mpn
+    from mtmc_mpn import _lib, engine
+    m = mtmc_mpn.MOTMPNet(mtmc_mpn.default_params(num_enc_steps=3), None, "resnet101")
+    lib = _lib.load()
+    eng = engine.ForwardEngine(m)
+    model = _lib.Model()
+    # host pointers are fine here: the sizing entry points only read dimensions
+    model = eng.model_struct(next(m.parameters()).device)
+    small = lib.mtmc_mpn_workspace_bytes(ctypes.byref(model), 450, 150454)
+    big = lib.mtmc_mpn_workspace_bytes(ctypes.byref(model), 100000, 10000000)
+    train = lib.mtmc_mpn_train_workspace_bytes(ctypes.byref(model), 450, 150454)
+    assert 0 < small < train and small < big
+    assert 40 * 10000000 < big < 200 * 10000000 + 100000 * 9000
+    lay = _lib.WsLayout()
+    assert lib.mtmc_mpn_workspace_layout(ctypes.byref(model), 450, 150454, ctypes.byref(lay)) == 0
+    assert lay.total_bytes == small and lay.zero_bytes < lay.h0_off
