@@ -305,7 +305,7 @@ def run_training_step(device):
     e = data.edge_index.shape[1]
     return {"workload": "training-scene topology, 100 identities: forward(Dropout)+CE+backward+SGD, L=3 Cs=3",
             "N": int(data.x.shape[0]), "E": int(e), "ms_per_step": sec * 1e3, "edges_per_s": e / sec,
-            "final_loss": float(loss)}
+            "final_loss": float(loss.detach())}
 
 
 def main():
