@@ -69,6 +69,29 @@ def algorithmic_bytes_forward(n, e, L, cs, f=2048):
     return (f * 4 + 128) * n + 24 * e + L * (176 * e + 256 * n) + cs * 8 * e
 
 
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summaries (profiles/r01_<workload>_pmc_*.txt,
+    made by tools/pmc_summary.py from separate FETCH_SIZE and WRITE_SIZE passes of tools/fwd_loop.py on the same
+    workload).  Units are KB; on gfx950 FETCH_SIZE counts wide (16 B/lane) streaming reads at one half
+    (MI355X_MICROARCH.md, HBM), so reads are doubled; WRITE_SIZE is exact.  None when no summary is committed."""
+    tot = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        path = os.path.join(ROOT, "profiles", f"r01_{workload}_pmc_{ctr}.txt")
+        if not os.path.exists(path):
+            return None
+        num = den = 0.0
+        for line in open(path):
+            parts = line.split()
+            if len(parts) >= 5 and parts[0].startswith(kernel) and ctr in parts:
+                calls, avg = float(parts[-2]), float(parts[-1])
+                num += calls * avg
+                den += calls
+        if den == 0:
+            return None
+        tot[ctr] = num / den
+    return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0
+
+
 def encoder_kernel(n_rows, layer):
     """Which GEMM kernel csrc/gemm_bn.hip:gemm_plan picks for an encoder layer (mirrors its rule)."""
     big = ((n_rows + 127) // 128) * ((layer.out_dim + 127) // 128) >= 512 and layer.out_dim >= 128
@@ -223,6 +246,10 @@ def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
                 "algorithmic_per_launch": work}
     if peak_note:
         roofline["peak_note"] = peak_note
+    roofline["traffic"] = pmc_traffic(name, dom_key)
+    if roofline["traffic"] is not None:
+        roofline["traffic_note"] = ("HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01_%s_pmc_*.txt "
+                                    "(separate rocprofv3 --pmc passes; gfx950 half-count correction on reads)" % name)
     b_fwd = algorithmic_bytes_forward(n, e, L, cs)
     phases = {}
     for (ph, arg), t in zip(seq, ms):
