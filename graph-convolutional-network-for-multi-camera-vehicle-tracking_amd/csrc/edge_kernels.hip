@@ -11,6 +11,7 @@
 //   pass_b_kernel      e' = relu(bn(z1)) stored; moments of e'; per-node segment sums of e'
 //   pass_c_kernel      m = relu(bn(Wn.[h[row]|e'] + bn)); h' = agg_row(m); logits  (NodeModel, mpn.py:97-99)
 //   classify_e0_kernel logits of the encoded edges when L == 0                      (mpn.py:295-297)
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace mtmc {
@@ -139,8 +140,10 @@ __device__ __forceinline__ void edge_z1(const RoundParams& p, const EdgeEncAffin
   }
 }
 
-constexpr int kEPT = 4;   // edges per thread and loop trip in passes A/B: four independent load chains in flight
+// kEPT = edges per thread and loop trip in passes A/B: four independent load chains in flight on big graphs, one on
+// small ones, where filling the 256 CUs with waves matters more (pick_ept)
 
+template <int kEPT>
 __global__ __launch_bounds__(256) void pass_a_kernel(RoundParams p) {
   __shared__ EdgeEncAffine af;
   __shared__ double red[8 * 4];
@@ -177,9 +180,30 @@ __global__ __launch_bounds__(256) void pass_a_kernel(RoundParams p) {
 }
 
 // e' = relu(bn(z1)) in place; second moments of e'; per-node segment sums of e'
+template <int kEPT>
 __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
   __shared__ float s1[4], t1[4];
   __shared__ double red[14 * 4];
+  const int lane = threadIdx.x & 63;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * kEPT;
+  const int64_t e_end = ((p.n_edges + 63) / 64) * 64;
+  int64_t base = (int64_t)blockIdx.x * blockDim.x * kEPT + threadIdx.x;
+  // the first trip's operands do not depend on the statistics: fetch them before waiting for those
+  int rr[kEPT];
+  float4 zz[kEPT];
+  auto fetch = [&](int64_t b) {
+#pragma unroll
+    for (int i = 0; i < kEPT; ++i) {
+      const int64_t e = b + i * 256;
+      rr[i] = -1;
+      zz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < p.n_edges) {
+        rr[i] = p.row32[e];
+        zz[i] = reinterpret_cast<const float4*>(p.e_buf)[e];
+      }
+    }
+  };
+  if (base < e_end) fetch(base);
   stat_gather(p.stats + kRoundZ1Off, 8, kZ1Stride, red);
   __syncthreads();
   if (threadIdx.x < 4) {
@@ -190,25 +214,18 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
   double acc[14];
 #pragma unroll
   for (int i = 0; i < 14; ++i) acc[i] = 0;
-  const int lane = threadIdx.x & 63;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x * kEPT;
-  const int64_t e_end = ((p.n_edges + 63) / 64) * 64;
-  for (int64_t base = (int64_t)blockIdx.x * blockDim.x * kEPT + threadIdx.x; base < e_end; base += stride) {
-    int rr[kEPT];
+  while (base < e_end) {
     float vv[kEPT][4];
 #pragma unroll
     for (int i = 0; i < kEPT; ++i) {
       const int64_t e = base + i * 256;
-      rr[i] = -1;
 #pragma unroll
       for (int k = 0; k < 4; ++k) vv[i][k] = 0.f;
       if (e < p.n_edges) {
-        rr[i] = p.row32[e];
-        const float4 z = reinterpret_cast<const float4*>(p.e_buf)[e];
-        const float zz[4] = {z.x, z.y, z.z, z.w};
+        const float z4[4] = {zz[i].x, zz[i].y, zz[i].z, zz[i].w};
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          vv[i][k] = drop_apply(p.drop_e, p.drop_stream, (unsigned long long)e * 4 + k, fmaxf(fmaf(zz[k], s1[k], t1[k]), 0.f));
+          vv[i][k] = drop_apply(p.drop_e, p.drop_stream, (unsigned long long)e * 4 + k, fmaxf(fmaf(z4[k], s1[k], t1[k]), 0.f));
         reinterpret_cast<float4*>(p.e_out)[e] = make_float4(vv[i][0], vv[i][1], vv[i][2], vv[i][3]);
       }
     }
@@ -260,6 +277,8 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
         for (int k = 0; k < 4; ++k) unsafeAtomicAdd(p.seg + (int64_t)r * 4 + k, (double)v[k]);
       }
     }
+    base += stride;
+    if (base < e_end) fetch(base);
   }
   block_atomic_add<14>(acc, p.stats + kRoundMOff, kMStride, red);
 }
@@ -267,7 +286,6 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
 // ------------------------------------------------------------------------------------------------
 // pass C: 32 lanes = 32 channels; every half-wave walks 32 consecutive edges of the block's tile
 // ------------------------------------------------------------------------------------------------
-constexpr int kTileC = 256;
 
 // Order-independent aggregation for row-sorted lists (MTMC_F_DETERMINISTIC): a 32-edge chunk's first run goes to
 // carry[chunk][0], its last run (if different) to carry[chunk][1], runs strictly inside the chunk are complete rows
@@ -313,12 +331,28 @@ __global__ __launch_bounds__(256) void agg_fixup_kernel(RoundParams p) {
   }
 }
 
-__global__ __launch_bounds__(256) void pass_c_kernel(RoundParams p) {
+constexpr int kTileC = 256;   // tile = block size (128 and 512 measured slower at every graph size)
+__global__ __launch_bounds__(kTileC) void pass_c_kernel(RoundParams p) {
   __shared__ float4 tile_e[kTileC];
   __shared__ int tile_row[kTileC];
   __shared__ double st[10 + 64];           // e' second moments (10) | z2 sums (32) | z2 sums of squares (32)
   const int k = threadIdx.x & 31;          // channel
-  const int hw = threadIdx.x >> 5;         // half-wave 0..7
+  const int hw = threadIdx.x >> 5;         // half-wave
+  const int64_t n_tiles = (p.n_edges + kTileC - 1) / kTileC;
+  int64_t tile = blockIdx.x;
+  // a tile's operands do not depend on the statistics: fetch the first one before waiting for those
+  float4 ev;
+  int rw;
+  auto fetch = [&](int64_t t) {
+    const int64_t e = t * kTileC + threadIdx.x;
+    ev = make_float4(0, 0, 0, 0);
+    rw = 0;
+    if (e < p.n_edges) {
+      ev = reinterpret_cast<const float4*>(p.e_out)[e];
+      rw = p.row32[e];
+    }
+  };
+  if (tile < n_tiles) fetch(tile);
   // BatchNorm affine of channel k of z2 from the moment statistics (node_stat_kernel + pass B)
   stat_gather(p.stats + kRoundMOff + 4, 10, kMStride, st);
   stat_gather(p.stats + kRoundZ2Off, 64, kZ2Stride, st + 10);
@@ -335,14 +369,11 @@ __global__ __launch_bounds__(256) void pass_c_kernel(RoundParams p) {
   const float cb = fmaf(sk, p.un_b[k], tk);
   const bool det = p.det && p.agg != 2 && p.flags[0] == 0;      // max is order-independent as it is
 
-  const int64_t n_tiles = (p.n_edges + kTileC - 1) / kTileC;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  while (tile < n_tiles) {
     const int64_t base = tile * kTileC;
     const int64_t e = base + threadIdx.x;
-    float4 ev = make_float4(0, 0, 0, 0);
     if (e < p.n_edges) {
-      ev = reinterpret_cast<const float4*>(p.e_out)[e];
-      tile_row[threadIdx.x] = p.row32[e];
+      tile_row[threadIdx.x] = rw;
       if (p.logits) {                                         // classifier on this edge (mpn.py:291-292)
         float lg[MTMC_MAX_CLASSES];
         for (int c = 0; c < p.n_classes; ++c) {
@@ -377,6 +408,8 @@ __global__ __launch_bounds__(256) void pass_c_kernel(RoundParams p) {
       acc = (p.agg == 2) ? fmaxf(acc, m) : acc + m;
     }
     if (cur >= 0) flush_run(p, det, chunk, first ? 0 : 1, cur, k, acc);
+    tile += gridDim.x;
+    if (tile < n_tiles) fetch(tile);
     __syncthreads();
   }
 }
@@ -410,6 +443,11 @@ static inline int edge_grid(int64_t n_edges, int per_block) {
   return (int)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
 }
 
+// Below this many edges a pass at 4 edges/thread would leave most of the 256 CUs with one or two waves: use the
+// finest decomposition there (measured on camera graphs of 50k..12M edges, tools/size_sweep.py).
+constexpr int64_t kSmallEdges = 2048 * 256;
+static inline int pick_ept(int64_t n_edges) { return n_edges <= kSmallEdges ? 1 : 4; }
+
 void launch_prep(const PrepParams& p, hipStream_t s) {
   hipLaunchKernelGGL(prep_kernel, dim3(edge_grid(p.n_edges, 256)), dim3(256), 0, s, p);
 }
@@ -419,13 +457,19 @@ void launch_enc2(const EdgeEncParams& enc, const float* attr, int64_t n_edges, d
                      stat_enc2);
 }
 void launch_pass_a(const RoundParams& p, hipStream_t s) {
-  hipLaunchKernelGGL(pass_a_kernel, dim3(edge_grid(p.n_edges, 256 * kEPT)), dim3(256), 0, s, p);
+  switch (pick_ept(p.n_edges)) {
+    case 1: hipLaunchKernelGGL(pass_a_kernel<1>, dim3(edge_grid(p.n_edges, 256)), dim3(256), 0, s, p); break;
+    default: hipLaunchKernelGGL(pass_a_kernel<4>, dim3(edge_grid(p.n_edges, 1024)), dim3(256), 0, s, p);
+  }
 }
 void launch_pass_b(const RoundParams& p, hipStream_t s) {
-  hipLaunchKernelGGL(pass_b_kernel, dim3(edge_grid(p.n_edges, 256 * kEPT)), dim3(256), 0, s, p);
+  switch (pick_ept(p.n_edges)) {
+    case 1: hipLaunchKernelGGL(pass_b_kernel<1>, dim3(edge_grid(p.n_edges, 256)), dim3(256), 0, s, p); break;
+    default: hipLaunchKernelGGL(pass_b_kernel<4>, dim3(edge_grid(p.n_edges, 1024)), dim3(256), 0, s, p);
+  }
 }
 void launch_pass_c(const RoundParams& p, hipStream_t s) {
-  hipLaunchKernelGGL(pass_c_kernel, dim3(edge_grid(p.n_edges, kTileC)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(pass_c_kernel, dim3(edge_grid(p.n_edges, kTileC)), dim3(kTileC), 0, s, p);
   if (p.det && p.agg != 2) {
     const int64_t blocks = (p.n_nodes + 7) / 8;
     hipLaunchKernelGGL(agg_fixup_kernel, dim3((int)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks))), dim3(256), 0, s, p);
