@@ -58,7 +58,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "lib
 EXPORTS = ["mtmc_mpn_abi_version", "mtmc_mpn_last_error", "mtmc_mpn_workspace_bytes", "mtmc_mpn_workspace_layout",
            "mtmc_mpn_forward", "mtmc_mpn_run_phase", "mtmc_scatter_add", "mtmc_scatter_mean", "mtmc_scatter_max",
            "mtmc_mlp_layer_forward", "mtmc_mpn_train_workspace_bytes", "mtmc_mpn_backward", "mtmc_graph_workspace_bytes",
-           "mtmc_build_graph"]
+           "mtmc_build_graph", "mtmc_postprocess_workspace_bytes", "mtmc_postprocess"]
 
 _lib = None
 
@@ -91,6 +91,12 @@ def load() -> C.CDLL:
     lib.mtmc_build_graph.restype = C.c_int32
     lib.mtmc_build_graph.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 5 + \
         [C.c_int32, C.c_int64] + [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p]
+    lib.mtmc_postprocess_workspace_bytes.restype = C.c_size_t
+    lib.mtmc_postprocess_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int64]
+    lib.mtmc_postprocess.restype = C.c_int32
+    lib.mtmc_postprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
+                                     C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_size_t, C.c_void_p]
     lib.mtmc_mpn_run_phase.restype = C.c_int32
     lib.mtmc_mpn_run_phase.argtypes = [C.POINTER(Model), C.POINTER(Call), C.c_int32, C.c_int32]
     for name in ("mtmc_scatter_add",):

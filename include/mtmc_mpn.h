@@ -22,6 +22,8 @@
  *   mtmc_scatter_{add,mean,max}<- torch_scatter.scatter_{add,mean,max}(src, index, dim=0, dim_size)
  *                                 (third-party pytorch-scatter 2.0.8; call sites models/mpn.py:196,199,202)
  *   mtmc_mlp_forward           <- MLP.forward as a stand-alone op  models/mlp.py:32-33
+ *   mtmc_build_graph           <- graph construction around the call  inference.py:402-456, train.py:316-342
+ *   mtmc_postprocess           <- softmax/argmax + post_processing    inference.py:475-489, :70-169; utils.py:30-339
  *
  * All floating tensors are fp32, row-major, contiguous unless a stride argument says otherwise;
  * BatchNorm statistics are accumulated in fp64.  All work is enqueued on `stream` (a hipStream_t
@@ -201,6 +203,25 @@ int32_t mtmc_build_graph(const float* feats, int64_t feat_row_stride, int64_t n_
                          const int32_t* in_list, const int32_t* in_off, const int32_t* out_list, const int64_t* out_off,
                          const int64_t* block_off, int32_t n_cams, int64_t n_edges, const int64_t* node_labels,
                          float* x_out, int64_t* edge_index_out, float* edge_attr_out, float* edge_labels_out,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- post-processing of the last logits (replaces reference inference.py:475-489, post_processing
+ * inference.py:70-169 and utils.py compute_SCC_and_Clusters :30-52, splitting :54-123, remove_edges_single_direction
+ * :125-142, pruning :144-339) ----
+ * logits [E][2] -> prob1 [E] = softmax(logits)[:,1] and predictions [E] = argmax (both written); then, per `flags`,
+ * symmetric cut, flow pruning (at most num_cameras-1 active out-/in-edges per node), second cut, splitting of clusters
+ * with more than num_cameras nodes; predictions is updated in place and id_pred [N] receives the cluster number of
+ * every node in the reference's numbering (networkx SCC emission order, stably sorted by size, isolated nodes last).
+ * logits == NULL: prob1 and predictions are INPUTS (reproduces a run from given probabilities exactly).
+ * info [8] (int32, device): active edges in, active edges out, clusters, status (0 ok, 1 = more than max_active
+ * active edges: predictions left at argmax, 2 = over-sized cluster without an active edge), splitting iterations,
+ * component walks, pruning rounds.  max_active <= 0: size the workspace for E active edges.
+ * row/col: int64 with element stride idx_stride, as in struct mtmc_mpn_call.  Nothing is synchronised or allocated. */
+enum { MTMC_PP_CUTTING = 1, MTMC_PP_PRUNING = 2, MTMC_PP_SPLITTING = 4 };
+size_t mtmc_postprocess_workspace_bytes(int64_t n_nodes, int64_t n_edges, int64_t max_active);
+int32_t mtmc_postprocess(const float* logits, const int64_t* row, const int64_t* col, int64_t idx_stride,
+                         int64_t n_nodes, int64_t n_edges, int32_t num_cameras, int32_t flags, int64_t max_active,
+                         float* prob1, int64_t* predictions, int64_t* id_pred, int32_t* info,
                          void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus

@@ -1,0 +1,2 @@
+def to_networkx(*a, **k):      # name only; see the package docstring
+    raise NotImplementedError("placeholder")
