@@ -298,6 +298,48 @@ def run_graph_build(device, with_cpu=True):
     return out
 
 
+def run_postprocess(device, with_cpu=True):
+    """last logits -> (predictions, ID_pred), S02-scale scenario (the pp8 fixture's recipe)."""
+    from mtmc_mpn import pp_cases
+    kw = dict(n_ids=140, n_cams=4, seed=20, fp_rate=0.0005, fn_rate=0.05, pair_fp=0.0006)
+    sc = pp_cases.scenario(**kw)
+    logits, ei = sc.logits.to(device), sc.edge_index.to(device)
+    for _ in range(3):
+        out = mtmc_mpn.postprocess(logits, ei, sc.n_nodes, sc.n_cams)
+    info = out.info
+    torch.cuda.synchronize(device)
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = mtmc_mpn.postprocess(logits, ei, sc.n_nodes, sc.n_cams, check=False)
+    torch.cuda.synchronize(device)
+    sec = (time.perf_counter() - t0) / reps
+    # the same graph with a cleaner classifier (few over-sized clusters): what a trained model's output looks like
+    sc2 = pp_cases.scenario(**dict(kw, fp_rate=0.0002, pair_fp=0.00005))
+    l2, e2 = sc2.logits.to(device), sc2.edge_index.to(device)
+    info2 = mtmc_mpn.postprocess(l2, e2, sc2.n_nodes, sc2.n_cams).info
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        mtmc_mpn.postprocess(l2, e2, sc2.n_nodes, sc2.n_cams, check=False)
+    torch.cuda.synchronize(device)
+    sec2 = (time.perf_counter() - t0) / reps
+    res = {"workload": "S02-scale synthetic logits (pp8 fixture recipe): softmax/argmax, cut, pruning, cut, splitting, SCC",
+           "N": sc.n_nodes, "E": int(ei.shape[1]), "ms_per_call": sec * 1e3, "edges_per_s": ei.shape[1] / sec, **info,
+           "clean_case": {"ms_per_call": sec2 * 1e3, **info2},
+           "replaces": "inference.py:475-489 + post_processing :70-169 + utils.py:30-339 (D2H of the edge list, Python "
+                       "list scans, networkx SCC per splitting iteration)"}
+    if with_cpu:
+        from oracle import postprocess_oracle as po
+        t0 = time.perf_counter()
+        prob, pred = po.classify(sc.logits)
+        po.post_processing(sc.n_cams, pred, sc.edge_index, sc.n_nodes, prob)
+        res["cpu_oracle_ms"] = (time.perf_counter() - t0) * 1e3
+        res["cpu_note"] = ("oracle = the reference's algorithm with set/array lookups instead of its O(A^2) list scans; the "
+                           "reference's own post_processing took 9.3 s on this case in the build container (8 cores)")
+    return res
+
+
 def run_training_step(device):
     """BASELINE config 3 shape: 100 identities of the training scenes (N~430, E~173k), L=3, Cs=3, forward with
     Dropout + cross-entropy over the classified steps + backward + SGD step (lr 0.01, momentum 0.9, wd 1e-4)."""
@@ -371,6 +413,7 @@ def main():
         line["scale_base"] = run_single("cfg5", device, 5, 2, with_cpu=False, phase_iters=2)
         line["graph_build"] = run_graph_build(device, with_cpu=not args.no_cpu)
         line["training_step"] = run_training_step(device)
+        line["postprocess"] = run_postprocess(device, with_cpu=not args.no_cpu)
     print(json.dumps(line))
 
 

@@ -27,7 +27,7 @@ constexpr int kPpChunk = 1024;            // edges per block in the wide kernels
 constexpr int kPpThreads = 1024;          // the graph kernel's workgroup
 constexpr int kPpLdsNodes = 2048;         // LDS-resident graph state up to this many nodes ...
 constexpr int kPpLdsEdges = 16384;        // ... and this many active edges
-constexpr int kPpStage = 1024;            // active edges staged per step of the source scan
+constexpr int kPpNodeArrays = 9;          // rowptr, label, t0..t6
 constexpr unsigned kDead = 0x80000000u;
 
 struct PpParams {
@@ -41,7 +41,7 @@ struct PpParams {
   int32_t* info;                          // [8]: A_in, A_out, clusters, status, split iterations, scc walks, prune rounds
   // workspace
   int* hdr; int* block_count; int* a_idx; int* a_u; int* a_v; float* a_p; int* a_slot; unsigned char* alive;
-  unsigned char* mark; int* g_node; unsigned* g_csr; int64_t cap;
+  unsigned char* mark; int* g_node; unsigned* g_csr; int* g_flags; int* b_idx; int* b_u; int* b_v; float* b_p; int64_t cap;
 };
 
 __device__ __forceinline__ float softmax_p1(float l0, float l1) {
@@ -108,6 +108,7 @@ __global__ __launch_bounds__(1024) void pp_scan_kernel(PpParams p, int n_blocks)
   const int total = block_exclusive_scan(p.block_count, n_blocks, sh);
   if (threadIdx.x == 0) {
     p.hdr[0] = total;
+    p.hdr[2] = 0;
     p.hdr[1] = total > p.cap ? 1 : 0;                   // more active edges than the workspace was sized for
     p.info[0] = total;
   }
@@ -149,7 +150,7 @@ struct PpGraph {
   // N-sized
   int* rowptr;     // [N+1] CSR over ALL compacted active edges, rows in ascending active id (= edge order)
   int* label;      // [N]   cluster number of the node's component (output numbering)
-  int* t0; int* t1; int* t2; int* t3; int* t4; int* t5;   // [N] each, phase-dependent (see uses)
+  int* t0; int* t1; int* t2; int* t3; int* t4; int* t5; int* t6;   // [N] each, phase-dependent (see uses)
   unsigned* csr;   // [A]   target node | kDead
   int n, a, cams;
 };
@@ -248,70 +249,106 @@ __device__ int pp_prune(const PpParams& p, const PpGraph& g) {
   }
 }
 
-// utils.py:30-52.  Strongly connected components in the order networkx emits them
-// (nx.strongly_connected_components: sources in node insertion order = first appearance in the active edge list,
-// successors in insertion order, a component is emitted when its root finishes), stably sorted by size; nodes
-// without an active edge follow as singletons in index order.  label[v] = position of v's set; returns the number
-// of sets; sizes by label in t5.  The walk itself is lane 0's; the rest of the block stages the source list.
-__device__ int pp_scc(const PpParams& p, const PpGraph& g, int* stage_u, int* stage_v, int* sh) {
-  int* pre = g.t0; int* low = g.t1; int* comp = g.t2; int* cursor = g.t3; int* dstack = g.t4; int* sstack = g.t5;
-  for (int n = threadIdx.x; n < g.n; n += blockDim.x) { pre[n] = 0; comp[n] = -1; cursor[n] = g.rowptr[n]; }
-  __syncthreads();
-  int counter = 0, n_comp = 0, stop = 0;                 // lane 0's state
-  for (int base = 0; base < g.a; base += kPpStage) {
-    for (int i = threadIdx.x; i < kPpStage; i += blockDim.x) {
-      const int k = base + i;
-      const bool on = k < g.a && p.alive[k];
-      stage_u[i] = on ? p.a_u[k] : -1;
-      stage_v[i] = on ? p.a_v[k] : -1;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const int cnt = min(kPpStage, g.a - base);
-      for (int i = 0; i < 2 * cnt; ++i) {
-        const int source = (i & 1) ? stage_v[i >> 1] : stage_u[i >> 1];
-        if (source < 0 || pre[source] != 0) continue;
-        int dtop = 0;
-        dstack[dtop++] = source;
-        while (dtop) {
-          const int v = dstack[dtop - 1];
-          if (pre[v] == 0) { pre[v] = ++counter; sstack[stop++] = v; }
-          bool descended = false;
-          const int end = g.rowptr[v + 1];
-          int c = cursor[v];
-          while (c < end) {
-            const unsigned t = g.csr[c++];
-            if (t & kDead) continue;
-            if (pre[t] == 0) { dstack[dtop++] = (int)t; descended = true; break; }
-          }
-          cursor[v] = c;
-          if (descended) continue;
-          int lv = pre[v];
-          for (int s = g.rowptr[v]; s < end; ++s) {
-            const unsigned t = g.csr[s];
-            if (t & kDead) continue;
-            if (comp[t] >= 0) continue;                  // already in an emitted component
-            lv = min(lv, pre[t] > pre[v] ? low[t] : pre[t]);
-          }
-          low[v] = lv;
-          --dtop;
-          if (lv == pre[v]) {
-            int w;
-            do { w = sstack[--stop]; comp[w] = n_comp; } while (w != v);
-            ++n_comp;
-          }
-        }
+// Lane 0's part of utils.py:30-52: nx.strongly_connected_components' traversal (sources in node insertion order,
+// successors in insertion order, a component is emitted when its root finishes -- Tarjan's algorithm; networkx
+// evaluates the lowlinks at finish time, here they are folded into the single pass over the successors, which finds
+// the same roots in the same order) and the stable placement of the emitted components by size.  Templated on the pointer types
+// so that the LDS-resident case compiles to ds_read/ds_write instead of flat accesses.
+template <typename IP, typename UP>
+__device__ int pp_walk(IP rowptr, IP pre, IP low, IP comp, IP cursor, IP dstack, IP sstack, UP csr, IP src, int n_src) {
+  int counter = 0, n_comp = 0, stop = 0;
+  for (int i = 0; i < n_src; ++i) {
+    const int source = src[i];
+    if (pre[source] != 0) continue;
+    int dtop = 0;
+    dstack[dtop++] = source;
+    pre[source] = low[source] = ++counter;
+    sstack[stop++] = source;
+    while (dtop) {
+      const int v = dstack[dtop - 1];
+      const int end = rowptr[v + 1];
+      int c = cursor[v], lv = low[v];
+      int child = -1;
+      while (c < end) {
+        const unsigned t = csr[c++];
+        if (t & kDead) continue;
+        const int pt = pre[t];
+        if (pt == 0) { child = (int)t; break; }
+        if (comp[t] < 0) lv = min(lv, pt);               // still on the component stack
+      }
+      cursor[v] = c;
+      low[v] = lv;
+      if (child >= 0) {
+        dstack[dtop++] = child;
+        pre[child] = low[child] = ++counter;
+        sstack[stop++] = child;
+        continue;
+      }
+      --dtop;
+      if (dtop) {                                        // tree edge parent -> v: hand the lowlink up
+        const int par = dstack[dtop - 1];
+        if (lv < low[par]) low[par] = lv;
+      }
+      if (lv == pre[v]) {
+        int w;
+        do { w = sstack[--stop]; comp[w] = n_comp; } while (w != v);
+        ++n_comp;
       }
     }
-    __syncthreads();
   }
-  __shared__ int s_ncomp;
-  if (threadIdx.x == 0) s_ncomp = n_comp;
+  return n_comp;
+}
+
+template <typename IP>
+__device__ void pp_place(IP clabel, IP hist, IP csize, int n_comp) {
+  for (int k = 0; k < n_comp; ++k) clabel[k] = hist[csize[k] - 1]++;
+}
+
+typedef __attribute__((address_space(3))) int* LdsIntPtr;
+typedef __attribute__((address_space(3))) unsigned* LdsUintPtr;
+
+// utils.py:30-52.  Strongly connected components in the order networkx emits them, stably sorted by size; nodes
+// without an active edge follow as singletons in index order.  label[v] = position of v's set; returns the number
+// of sets; sizes by label in t5.  All lanes prepare the ordered source list and the numbering; the walk is lane 0's.
+__device__ int pp_scc(const PpParams& p, const PpGraph& g, bool nodes_in_lds, bool csr_in_lds, int* sh) {
+  int* pre = g.t0; int* low = g.t1; int* comp = g.t2; int* cursor = g.t3; int* dstack = g.t4; int* sstack = g.t5;
+  int* src = g.t6;
+  int* first_pos = low;                                  // until the walk starts
+  for (int n = threadIdx.x; n < g.n; n += blockDim.x) {
+    pre[n] = 0; comp[n] = -1; cursor[n] = g.rowptr[n]; first_pos[n] = 0x7fffffff;
+  }
+  for (int i = threadIdx.x; i < 2 * g.a; i += blockDim.x) p.g_flags[i] = 0;
   __syncthreads();
-  n_comp = s_ncomp;
-  // sizes per emitted component (t3), histogram of sizes (t4, sizes 1..N), stable placement by size (lane 0)
-  int* csize = g.t3; int* hist = g.t4; int* clabel = g.t0; int* lsize = g.t5;
-  for (int n = threadIdx.x; n < g.n; n += blockDim.x) { csize[n] = 0; hist[n] = 0; }
+  // node insertion order of nx.DiGraph(active edge list): first appearance, u before v within an edge
+  for (int k = threadIdx.x; k < g.a; k += blockDim.x) {
+    if (!p.alive[k]) continue;
+    atomicMin(&first_pos[p.a_u[k]], 2 * k);
+    atomicMin(&first_pos[p.a_v[k]], 2 * k + 1);
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < g.n; n += blockDim.x)
+    if (first_pos[n] != 0x7fffffff) p.g_flags[first_pos[n]] = 1;
+  __syncthreads();
+  const int n_src = block_exclusive_scan(p.g_flags, 2 * (int64_t)g.a, sh);
+  for (int n = threadIdx.x; n < g.n; n += blockDim.x)
+    if (first_pos[n] != 0x7fffffff) src[p.g_flags[first_pos[n]]] = n;
+  __syncthreads();
+  __shared__ int s_ncomp;
+  if (threadIdx.x == 0) {
+    const long long t_begin = wall_clock64();
+    if (nodes_in_lds && csr_in_lds)
+      s_ncomp = pp_walk((LdsIntPtr)g.rowptr, (LdsIntPtr)pre, (LdsIntPtr)low, (LdsIntPtr)comp, (LdsIntPtr)cursor,
+                        (LdsIntPtr)dstack, (LdsIntPtr)sstack, (LdsUintPtr)g.csr, (LdsIntPtr)src, n_src);
+    else
+      s_ncomp = pp_walk(g.rowptr, pre, low, comp, cursor, dstack, sstack, g.csr, src, n_src);
+    p.hdr[2] += (int)(wall_clock64() - t_begin);         // 100 MHz ticks spent walking (diagnostic, info[7])
+  }
+  __syncthreads();
+  const int n_comp = s_ncomp;
+  // sizes per emitted component (t3), histogram of sizes (t4, sizes 1..N), stable placement by size (lane 0),
+  // isolated nodes numbered after them in index order (scan over t1)
+  int* csize = g.t3; int* hist = g.t4; int* clabel = g.t0; int* lsize = g.t5; int* iso = g.t1;
+  for (int n = threadIdx.x; n < g.n; n += blockDim.x) { csize[n] = 0; hist[n] = 0; iso[n] = comp[n] < 0 ? 1 : 0; }
   __syncthreads();
   for (int n = threadIdx.x; n < g.n; n += blockDim.x)
     if (comp[n] >= 0) atomicAdd(&csize[comp[n]], 1);
@@ -319,28 +356,46 @@ __device__ int pp_scc(const PpParams& p, const PpGraph& g, int* stage_u, int* st
   for (int k = threadIdx.x; k < n_comp; k += blockDim.x) atomicAdd(&hist[csize[k] - 1], 1);
   __syncthreads();
   block_exclusive_scan(hist, g.n, sh);
-  __shared__ int s_total;
+  const int n_iso = block_exclusive_scan(iso, g.n, sh);
   if (threadIdx.x == 0) {
-    for (int k = 0; k < n_comp; ++k) clabel[k] = hist[csize[k] - 1]++;
-    int next = n_comp;
-    for (int n = 0; n < g.n; ++n)
-      if (comp[n] < 0) g.label[n] = next++;
-    s_total = next;
+    if (nodes_in_lds) pp_place((LdsIntPtr)clabel, (LdsIntPtr)hist, (LdsIntPtr)csize, n_comp);
+    else pp_place(clabel, hist, csize, n_comp);
   }
-  __syncthreads();
   for (int n = threadIdx.x; n < g.n; n += blockDim.x) lsize[n] = 1;
   __syncthreads();
-  for (int n = threadIdx.x; n < g.n; n += blockDim.x)
-    if (comp[n] >= 0) g.label[n] = clabel[comp[n]];
+  for (int n = threadIdx.x; n < g.n; n += blockDim.x) g.label[n] = comp[n] >= 0 ? clabel[comp[n]] : n_comp + iso[n];
   for (int k = threadIdx.x; k < n_comp; k += blockDim.x) lsize[clabel[k]] = csize[k];
   __syncthreads();
-  return s_total;
+  return n_comp + n_iso;
+}
+
+// Drop the dead edges from the active arrays (stable) once the cut / prune stages are over: the walks of the
+// splitting loop then step over ~A_alive instead of A_in slots.  Dead edges get their prediction cleared here.
+__device__ int pp_compact_alive(const PpParams& p, const PpGraph& g, int* sh) {
+  int* pos = p.g_flags;
+  for (int i = threadIdx.x; i < g.a; i += blockDim.x) pos[i] = p.alive[i] ? 1 : 0;
+  __syncthreads();
+  const int kept = block_exclusive_scan(pos, g.a, sh);
+  for (int i = threadIdx.x; i < g.a; i += blockDim.x) {
+    if (p.alive[i]) {
+      const int k = pos[i];
+      p.b_idx[k] = p.a_idx[i]; p.b_u[k] = p.a_u[i]; p.b_v[k] = p.a_v[i]; p.b_p[k] = p.a_p[i];
+    } else {
+      p.pred[p.a_idx[i]] = 0;
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < kept; k += blockDim.x) {
+    p.a_idx[k] = p.b_idx[k]; p.a_u[k] = p.b_u[k]; p.a_v[k] = p.b_v[k]; p.a_p[k] = p.b_p[k];
+    p.alive[k] = 1;
+  }
+  __syncthreads();
+  return kept;
 }
 
 __global__ __launch_bounds__(kPpThreads) void pp_graph_kernel(PpParams p, int lds_nodes) {
   extern __shared__ __attribute__((aligned(16))) int lds[];
   __shared__ int sh[kPpThreads / 64 + 1];
-  __shared__ int stage_u[kPpStage], stage_v[kPpStage];
   __shared__ unsigned s_min;
   __shared__ int s_lab;
   if (p.hdr[1]) {                                        // capacity exceeded: report, leave predictions = argmax
@@ -353,8 +408,10 @@ __global__ __launch_bounds__(kPpThreads) void pp_graph_kernel(PpParams p, int ld
   int* node_base = lds_nodes ? lds : p.g_node;
   g.rowptr = node_base; g.label = node_base + npad;
   g.t0 = node_base + 2 * npad; g.t1 = node_base + 3 * npad; g.t2 = node_base + 4 * npad; g.t3 = node_base + 5 * npad;
-  g.t4 = node_base + 6 * npad; g.t5 = node_base + 7 * npad;
-  g.csr = (g.a <= kPpLdsEdges) ? reinterpret_cast<unsigned*>(lds + (lds_nodes ? 8 * npad : 0)) : p.g_csr;
+  g.t4 = node_base + 6 * npad; g.t5 = node_base + 7 * npad; g.t6 = node_base + 8 * npad;
+  unsigned* lds_csr = reinterpret_cast<unsigned*>(lds + (lds_nodes ? kPpNodeArrays * npad : 0));
+  bool csr_in_lds = g.a <= kPpLdsEdges;
+  g.csr = csr_in_lds ? lds_csr : p.g_csr;
 
   pp_build_csr(p, g, sh);
   const bool cutting = p.flags & 1, pruning = p.flags & 2, splitting = p.flags & 4;
@@ -362,7 +419,13 @@ __global__ __launch_bounds__(kPpThreads) void pp_graph_kernel(PpParams p, int ld
   if (cutting) pp_cut(p, g);
   if (pruning) prune_rounds = pp_prune(p, g);
   if (cutting) pp_cut(p, g);
-  int n_sets = pp_scc(p, g, stage_u, stage_v, sh);
+  if (cutting || pruning) {
+    g.a = pp_compact_alive(p, g, sh);
+    csr_in_lds = g.a <= kPpLdsEdges;
+    g.csr = csr_in_lds ? lds_csr : p.g_csr;
+    pp_build_csr(p, g, sh);
+  }
+  int n_sets = pp_scc(p, g, lds_nodes != 0, csr_in_lds, sh);
   ++walks;
   if (splitting) {
     // utils.py:54-123, tail recursion unrolled: pick the first over-sized label; drop every edge whose probability
@@ -389,7 +452,7 @@ __global__ __launch_bounds__(kPpThreads) void pp_graph_kernel(PpParams p, int ld
         for (int i = threadIdx.x; i < g.a; i += blockDim.x)
           if (p.alive[i] && __float_as_uint(p.a_p[i]) == mn) pp_kill(p, g, i);
         __syncthreads();
-        n_sets = pp_scc(p, g, stage_u, stage_v, sh);
+        n_sets = pp_scc(p, g, lds_nodes != 0, csr_in_lds, sh);
         ++walks; ++split_iters;
         if (!(lsize[lab] > g.cams)) break;
       }
@@ -409,12 +472,12 @@ __global__ __launch_bounds__(kPpThreads) void pp_graph_kernel(PpParams p, int ld
   __syncthreads();
   if (threadIdx.x == 0) {
     p.info[1] = s_alive; p.info[2] = n_sets; p.info[3] = status; p.info[4] = split_iters; p.info[5] = walks;
-    p.info[6] = prune_rounds;
+    p.info[6] = prune_rounds; p.info[7] = p.hdr[2];
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-struct PpLayout { size_t hdr, block_count, a_idx, a_u, a_v, a_p, a_slot, alive, mark, g_node, g_csr, total; };
+struct PpLayout { size_t hdr, block_count, a_idx, a_u, a_v, a_p, a_slot, alive, mark, g_node, g_csr, g_flags, b_idx, b_u, b_v, b_p, total; };
 
 static PpLayout pp_layout(int64_t n_nodes, int64_t n_edges, int64_t cap) {
   PpLayout lo;
@@ -426,8 +489,10 @@ static PpLayout pp_layout(int64_t n_nodes, int64_t n_edges, int64_t cap) {
   lo.a_idx = take((size_t)cap * 4); lo.a_u = take((size_t)cap * 4); lo.a_v = take((size_t)cap * 4);
   lo.a_p = take((size_t)cap * 4); lo.a_slot = take((size_t)cap * 4);
   lo.alive = take((size_t)cap); lo.mark = take((size_t)cap);
-  lo.g_node = take((size_t)8 * (n_nodes + 4) * 4);
+  lo.g_node = take((size_t)kPpNodeArrays * (n_nodes + 4) * 4);
   lo.g_csr = take((size_t)cap * 4);
+  lo.g_flags = take((size_t)cap * 8);
+  lo.b_idx = take((size_t)cap * 4); lo.b_u = take((size_t)cap * 4); lo.b_v = take((size_t)cap * 4); lo.b_p = take((size_t)cap * 4);
   lo.total = off;
   return lo;
 }
@@ -454,17 +519,20 @@ int launch_postprocess(const float* logits, const int64_t* row, const int64_t* c
   p.a_slot = reinterpret_cast<int*>(ws + lo.a_slot); p.alive = reinterpret_cast<unsigned char*>(ws + lo.alive);
   p.mark = reinterpret_cast<unsigned char*>(ws + lo.mark); p.g_node = reinterpret_cast<int*>(ws + lo.g_node);
   p.g_csr = reinterpret_cast<unsigned*>(ws + lo.g_csr); p.cap = cap;
+  p.g_flags = reinterpret_cast<int*>(ws + lo.g_flags); p.b_idx = reinterpret_cast<int*>(ws + lo.b_idx);
+  p.b_u = reinterpret_cast<int*>(ws + lo.b_u); p.b_v = reinterpret_cast<int*>(ws + lo.b_v);
+  p.b_p = reinterpret_cast<float*>(ws + lo.b_p);
   const int nb = (int)((n_edges + kPpChunk - 1) / kPpChunk);
   if (nb > 0) hipLaunchKernelGGL(pp_classify_kernel, dim3(nb), dim3(256), 0, s, p);
   hipLaunchKernelGGL(pp_scan_kernel, dim3(1), dim3(1024), 0, s, p, nb);
   if (nb > 0) hipLaunchKernelGGL(pp_compact_kernel, dim3(nb), dim3(256), 0, s, p);
   const int lds_nodes = n_nodes <= kPpLdsNodes ? 1 : 0;
   const size_t npad = ((size_t)n_nodes + 4) & ~(size_t)3;
-  const size_t lds = (lds_nodes ? 8 * npad * sizeof(int) : 0) + (size_t)kPpLdsEdges * sizeof(unsigned);
+  const size_t lds = (lds_nodes ? kPpNodeArrays * npad * sizeof(int) : 0) + (size_t)kPpLdsEdges * sizeof(unsigned);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(pp_graph_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (8 * (kPpLdsNodes + 4) + kPpLdsEdges) * 4) != hipSuccess)
+                            (kPpNodeArrays * (kPpLdsNodes + 4) + kPpLdsEdges) * 4) != hipSuccess)
       return MTMC_E_HIP;
     attr_set = true;
   }

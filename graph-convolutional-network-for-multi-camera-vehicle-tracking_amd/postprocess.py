@@ -70,7 +70,7 @@ def postprocess(logits, edge_index, num_nodes: int, num_cameras: int, cutting=Tr
     if check:
         v = info.cpu().tolist()
         out.info = dict(active_in=v[0], active_out=v[1], clusters=v[2], status=v[3], split_iterations=v[4],
-                        component_walks=v[5], pruning_rounds=v[6])
+                        component_walks=v[5], pruning_rounds=v[6], walk_us=v[7] / 100.0)
         if v[3]:
             raise RuntimeError("mtmc_mpn.postprocess: " + _STATUS.get(v[3], f"status {v[3]}"))
     return out
