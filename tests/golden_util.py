@@ -1,4 +1,4 @@
-"""Shared helpers for the golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py)."""
+"""Shared helpers for the MPN golden fixtures (tests/golden/g*.npz, made by tests/golden/make_golden.py)."""
 import copy
 import glob
 import hashlib
@@ -16,7 +16,7 @@ ARCH = "resnet101"
 
 
 def case_names():
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "g[0-9]*.npz")))
 
 
 def sha(t: torch.Tensor) -> str:
