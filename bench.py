@@ -358,7 +358,7 @@ def run_training_step(device):
     def step():
         opt.zero_grad(set_to_none=True)
         out, _ = model(data)
-        loss = sum(torch.nn.functional.cross_entropy(o, labels) for o in out["classified_edges"])
+        loss = sum(mtmc_mpn.ops.cross_entropy(o, labels) for o in out["classified_edges"])
         loss.backward()
         opt.step()
         return loss

@@ -23,35 +23,52 @@ class _MpnFunction(torch.autograd.Function):
             _lib.check(engine.lib.mtmc_mpn_forward(C.byref(prep.model), C.byref(prep.call)))
         ctx.engine, ctx.prep = engine, prep
         ctx.need_x, ctx.need_attr = x.requires_grad, edge_attr.requires_grad
-        ctx.param_shapes = [p.shape for p in params]
         ctx.mark_non_differentiable(edge_index)
-        return prep.logits, prep.h
+        # one output per classified step: autograd then hands each step's gradient over as it is (no zeros + slice-adds)
+        return tuple(prep.logits[i] for i in range(prep.logits.shape[0])) + (prep.h,)
 
     @staticmethod
-    def backward(ctx, d_logits, d_h):
+    def backward(ctx, *grads_out):
         engine, prep = ctx.engine, ctx.prep
         dev = prep.dev
+        d_steps, d_h = grads_out[:-1], grads_out[-1]
+        # all 34 parameter gradients carved from one buffer: one allocation, one memset in the library
+        layers = list(engine.param_layers())
+        sizes = []
+        for _, lin, bn, _ in layers:
+            sizes += [lin.weight.numel(), lin.bias.numel()]
+            if bn is not None:
+                sizes += [bn.weight.numel(), bn.bias.numel()]
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + 63) // 64 * 64                       # 256-byte aligned pieces
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
         grads_struct = _lib.Model()
         grad_tensors = []
-        for (slot, idx), lin, bn, layer in engine.param_layers():
+        it = iter(offs)
+
+        def piece(like):
+            o = next(it)
+            t = flat[o:o + like.numel()].view(like.shape)
+            grad_tensors.append(t)
+            return t.data_ptr()
+        for (slot, idx), lin, bn, layer in layers:
             dst = getattr(grads_struct, slot) if idx is None else getattr(grads_struct, slot)[idx]
-            gw, gb = torch.empty_like(lin.weight), torch.empty_like(lin.bias)
-            dst.weight, dst.bias = gw.data_ptr(), gb.data_ptr()
-            grad_tensors += [gw, gb]
+            dst.weight, dst.bias = piece(lin.weight), piece(lin.bias)
             if bn is not None:
-                gg, gt = torch.empty_like(bn.weight), torch.empty_like(bn.bias)
-                dst.gamma, dst.beta = gg.data_ptr(), gt.data_ptr()
-                grad_tensors += [gg, gt]
+                dst.gamma, dst.beta = piece(bn.weight), piece(bn.bias)
             dst.in_dim, dst.out_dim = layer.in_dim, layer.out_dim
         dx = torch.empty((prep.n, engine.spec.enc_node[0].in_dim), device=dev) if ctx.need_x else None
         dattr = torch.empty((prep.e, engine.spec.enc_edge[0].in_dim), device=dev) if ctx.need_attr else None
-        dl = d_logits.contiguous().float() if d_logits is not None else None
+        keep = [g.contiguous().float() if g is not None else None for g in d_steps]
+        steps = (C.c_void_p * max(len(keep), 1))(*[g.data_ptr() if g is not None and g.numel() else None for g in keep])
         dh = d_h.contiguous().float() if d_h is not None else None
         with torch.cuda.device(dev):
             prep.call.stream = torch.cuda.current_stream(dev).cuda_stream
-            _lib.check(engine.lib.mtmc_mpn_backward(
-                C.byref(prep.model), C.byref(prep.call), dl.data_ptr() if dl is not None and dl.numel() else None,
-                dh.data_ptr() if dh is not None else None, C.byref(grads_struct),
+            _lib.check(engine.lib.mtmc_mpn_backward_steps(
+                C.byref(prep.model), C.byref(prep.call), steps, dh.data_ptr() if dh is not None else None,
+                C.byref(grads_struct), flat.data_ptr(), flat.numel() * 4,
                 dx.data_ptr() if dx is not None else None, dattr.data_ptr() if dattr is not None else None))
         return (None, None, None, dx, None, dattr) + tuple(grad_tensors)
 
@@ -70,6 +87,5 @@ def forward_with_tape(engine, x, edge_index, edge_attr, training):
     if engine.spec.num_enc_steps < 1:
         raise NotImplementedError("mtmc_mpn: backward with num_enc_steps == 0 is not implemented")
     seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if training else 0    # follows torch.manual_seed
-    logits, h = _MpnFunction.apply(engine, bool(training), seed, x, edge_index, edge_attr, *_ordered_params(engine))
-    n_out = logits.shape[0]
-    return [logits[i] for i in range(n_out)], h
+    out = _MpnFunction.apply(engine, bool(training), seed, x, edge_index, edge_attr, *_ordered_params(engine))
+    return list(out[:-1]), out[-1]

@@ -36,7 +36,8 @@ struct Layout {
   bool training;
   std::vector<size_t> z_tr, e_tr, h_tr;       // per round: z1 [E][4], e' [E][4], aggregated h [N][32]
   size_t g_e[2], g_e0, g_h[2], g_h0, g_P, g_Q, g_dz2, g_arg;   // gradients wrt e_r, e0, h_r, h0, P, Q; dz2 [E][32]
-  size_t bst;                                  // f64[kStatRep][kBwdStride] backward statistics scratch
+  size_t bst;                                  // f64[2L+1][kStatRep][kBwdStride] backward statistics blocks
+  size_t bwd_zero, bwd_zero_end;               // the range the backward clears with one memset
   size_t gA, gB, tA, tB, tW, zeros, bst_n;     // node-encoder backward: gradient ping-pong, transposes, 0-bias, column stats
 };
 constexpr int kBwdStride = 256;                // doubles per replica of the backward statistics scratch
@@ -116,28 +117,34 @@ inline void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* l
       lo->e_tr.push_back(take((size_t)E * 4 * sizeof(float)));
       lo->h_tr.push_back(take((size_t)N * 32 * sizeof(float)));
     }
-    for (int i = 0; i < 2; ++i) lo->g_e[i] = take((size_t)E * 4 * sizeof(float));
-    lo->g_e0 = take((size_t)E * 4 * sizeof(float));
-    for (int i = 0; i < 2; ++i) lo->g_h[i] = take((size_t)N * 32 * sizeof(float));
-    lo->g_h0 = take((size_t)N * 32 * sizeof(float));
-    lo->g_P = take((size_t)N * 8 * sizeof(float));
-    lo->g_Q = take((size_t)N * 32 * sizeof(float));
-    lo->g_dz2 = take((size_t)E * 32 * sizeof(float));
-    lo->g_arg = take((size_t)N * 32 * sizeof(int32_t));
-    lo->bst = take((size_t)mtmc::kStatRep * kBwdStride * sizeof(double));
-    size_t maxd = 0;
+    // everything the backward accumulates into, contiguous: ONE memset clears it (api_train.hip)
+    size_t maxd = 0, bn_stats = 0;
     for (int l = 0; l < m->n_enc_layers; ++l) {
       maxd = std::max(maxd, (size_t)m->enc_node[l].in_dim);
       maxd = std::max(maxd, (size_t)m->enc_node[l].out_dim);
+      bn_stats += 2 * (size_t)m->enc_node[l].out_dim;
     }
+    lo->bwd_zero = off;
+    lo->bst = take((size_t)(2 * L + 1) * mtmc::kStatRep * kBwdStride * sizeof(double));   // per round: node, edge; + encoder
+    lo->bst_n = take(bn_stats * sizeof(double));
+    lo->g_P = take((size_t)(L > 0 ? L : 1) * N * 8 * sizeof(float));      // per round
+    lo->g_Q = take((size_t)(L > 0 ? L : 1) * N * 32 * sizeof(float));     // per round
+    lo->zeros = take(maxd * sizeof(float));
+    lo->g_h0 = take((size_t)N * 32 * sizeof(float));
+    lo->g_e0 = take((size_t)E * 4 * sizeof(float));
+    lo->g_e[0] = take((size_t)E * 4 * sizeof(float));
+    lo->g_h[0] = take((size_t)N * 32 * sizeof(float));
+    lo->bwd_zero_end = off;
+    lo->g_e[1] = take((size_t)E * 4 * sizeof(float));
+    lo->g_h[1] = take((size_t)N * 32 * sizeof(float));
+    lo->g_dz2 = take((size_t)E * 32 * sizeof(float));
+    lo->g_arg = take((size_t)N * 32 * sizeof(int32_t));
     const size_t npad = (size_t)((N + 31) / 32 * 32);
     lo->gA = take((size_t)N * maxd * sizeof(float));
     lo->gB = take((size_t)N * maxd * sizeof(float));
     lo->tA = take(npad * maxd * sizeof(float));
     lo->tB = take(npad * maxd * sizeof(float));
     lo->tW = take(maxd * maxd * sizeof(float));
-    lo->zeros = take(maxd * sizeof(float));
-    lo->bst_n = take(2 * maxd * sizeof(double));
   }
   lo->pub.total_bytes = off;
 }

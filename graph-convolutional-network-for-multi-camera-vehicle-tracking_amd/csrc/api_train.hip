@@ -27,8 +27,9 @@ int check_grads(const mtmc_mpn_model* m, const mtmc_mpn_model* g) {
 
 }  // namespace
 
-extern "C" int32_t mtmc_mpn_backward(const mtmc_mpn_model* model, const mtmc_mpn_call* call, const float* d_logits,
-                                     const float* d_h, const mtmc_mpn_model* grads, float* d_x, float* d_edge_attr) {
+static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call, const float* const* d_logits_steps,
+                         const float* d_h, const mtmc_mpn_model* grads, void* grads_flat, size_t grads_flat_bytes,
+                         float* d_x, float* d_edge_attr) {
   Ctx x;
   if (int rc = make_ctx(model, call, &x)) return rc;
   if (!call->training) return fail(MTMC_E_ARG, "mtmc_mpn_backward needs the call of a training-mode forward");
@@ -38,25 +39,28 @@ extern "C" int32_t mtmc_mpn_backward(const mtmc_mpn_model* model, const mtmc_mpn
   if (L < 1) return fail(MTMC_E_ARG, "backward with num_enc_steps == 0 is not implemented");
   const int64_t N = call->n_nodes, E = call->n_edges;
   const int hn = (m->reattach_nodes ? 2 : 1) * MTMC_NODE_DIM;
-  const int C = m->cls.out_dim;
   hipStream_t s = x.stream;
   const Layout& lo = x.lo;
   double* bst = x.at<double>(lo.bst);
-  const size_t bst_bytes = (size_t)mtmc::kStatRep * kBwdStride * sizeof(double);
+  const size_t bst_block = (size_t)mtmc::kStatRep * kBwdStride;        // doubles per statistics block
   float* g_e[2] = {x.at<float>(lo.g_e[0]), x.at<float>(lo.g_e[1])};
   float* g_h[2] = {x.at<float>(lo.g_h[0]), x.at<float>(lo.g_h[1])};
   float* g_e0 = x.at<float>(lo.g_e0);
   float* g_h0 = x.at<float>(lo.g_h0);
 
-  // gradient buffers are accumulated into with atomics: clear them first (the caller only provides storage)
+  // gradient buffers are accumulated into with atomics: clear them first (the caller only provides storage).
+  // One memset when the caller carved all of them out of one buffer (grads_flat), else one per tensor; the node
+  // encoder's weight gradients are plain GEMM outputs and need none.
   auto zero = [&](float* p, size_t n) { return hipMemsetAsync(p, 0, n * sizeof(float), s); };
-  for (int l = 0; l < m->n_enc_layers; ++l) {
-    const mtmc_layer& g = grads->enc_node[l];
-    const size_t o = m->enc_node[l].out_dim, i = m->enc_node[l].in_dim;
-    HIP_OK(zero(const_cast<float*>(g.weight), o * i)); HIP_OK(zero(const_cast<float*>(g.bias), o));
-    HIP_OK(zero(const_cast<float*>(g.gamma), o)); HIP_OK(zero(const_cast<float*>(g.beta), o));
-  }
-  {
+  if (grads_flat) {
+    HIP_OK(hipMemsetAsync(grads_flat, 0, grads_flat_bytes, s));
+  } else {
+    for (int l = 0; l < m->n_enc_layers; ++l) {
+      const mtmc_layer& g = grads->enc_node[l];
+      const size_t o = m->enc_node[l].out_dim;
+      HIP_OK(zero(const_cast<float*>(g.bias), o));
+      HIP_OK(zero(const_cast<float*>(g.gamma), o)); HIP_OK(zero(const_cast<float*>(g.beta), o));
+    }
     const mtmc_layer* gs[] = {&grads->enc_edge[0], &grads->enc_edge[1], &grads->upd_edge, &grads->upd_node, &grads->cls};
     const mtmc_layer* ms[] = {&m->enc_edge[0], &m->enc_edge[1], &m->upd_edge, &m->upd_node, &m->cls};
     for (int i = 0; i < 5; ++i) {
@@ -65,10 +69,10 @@ extern "C" int32_t mtmc_mpn_backward(const mtmc_mpn_model* model, const mtmc_mpn
       if (i < 4) { HIP_OK(zero(const_cast<float*>(gs[i]->gamma), o)); HIP_OK(zero(const_cast<float*>(gs[i]->beta), o)); }
     }
   }
-  HIP_OK(zero(g_e[0], (size_t)E * 4)); HIP_OK(zero(g_e0, (size_t)E * 4)); HIP_OK(zero(g_h0, (size_t)N * 32));
+  // the workspace side: statistics blocks, per-round dP/dQ, dh0, de0, the first de / dh buffers -- one range
+  HIP_OK(hipMemsetAsync(x.ws + lo.bwd_zero, 0, lo.bwd_zero_end - lo.bwd_zero, s));
   int cur = 0, cur_e = 0;
   if (d_h) HIP_OK(hipMemcpyAsync(g_h[cur], d_h, (size_t)N * 32 * sizeof(float), hipMemcpyDeviceToDevice, s));
-  else HIP_OK(zero(g_h[cur], (size_t)N * 32));
 
   int first_cls = L - m->num_class_steps + 1;
   if (first_cls < 1) first_cls = 1;
@@ -91,24 +95,23 @@ extern "C" int32_t mtmc_mpn_backward(const mtmc_mpn_model* model, const mtmc_mpn
     bp.g_h = g_h[cur]; bp.h_agg = x.at<float>(lo.h_tr[r]); bp.deg = x.at<int>(lo.pub.deg_off);
     bp.arg = x.at<int>(lo.g_arg);
     const int step = r + 1;
-    bp.d_logits = (d_logits && step >= first_cls) ? d_logits + (size_t)(step - first_cls) * E * C : nullptr;
-    bp.g_dz2 = x.at<float>(lo.g_dz2); bp.g_Q = x.at<float>(lo.g_Q); bp.g_P = x.at<float>(lo.g_P);
-    bp.g_e = g_e[cur_e]; bp.g_e_prev = g_e[cur_e ^ 1]; bp.g_e0 = g_e0; bp.bst = bst;
+    bp.d_logits = (d_logits_steps && step >= first_cls) ? d_logits_steps[step - first_cls] : nullptr;
+    bp.g_dz2 = x.at<float>(lo.g_dz2);
+    bp.g_Q = x.at<float>(lo.g_Q) + (size_t)r * N * 32; bp.g_P = x.at<float>(lo.g_P) + (size_t)r * N * 8;
+    bp.g_e = g_e[cur_e]; bp.g_e_prev = g_e[cur_e ^ 1]; bp.g_e0 = g_e0; bp.bst = bst + (size_t)(2 * r) * bst_block;
     bp.gr_un_w = const_cast<float*>(grads->upd_node.weight); bp.gr_un_b = const_cast<float*>(grads->upd_node.bias);
     bp.gr_un_g = const_cast<float*>(grads->upd_node.gamma); bp.gr_un_bt = const_cast<float*>(grads->upd_node.beta);
     bp.gr_ue_w = const_cast<float*>(grads->upd_edge.weight); bp.gr_ue_b = const_cast<float*>(grads->upd_edge.bias);
     bp.gr_ue_g = const_cast<float*>(grads->upd_edge.gamma); bp.gr_ue_bt = const_cast<float*>(grads->upd_edge.beta);
     bp.gr_cls_w = const_cast<float*>(grads->cls.weight); bp.gr_cls_b = const_cast<float*>(grads->cls.bias);
 
-    HIP_OK(zero(bp.g_Q, (size_t)N * 32)); HIP_OK(zero(bp.g_P, (size_t)N * 8));
-    HIP_OK(hipMemsetAsync(bst, 0, bst_bytes, s));
     if (m->agg == MTMC_AGG_MAX) {
       HIP_OK(hipMemsetAsync(bp.arg, 0x7f, (size_t)N * 32 * sizeof(int32_t), s));
       mtmc::launch_bwd_node_upd(bp, 2, s);
     }
     mtmc::launch_bwd_node_upd(bp, 0, s);
     mtmc::launch_bwd_node_upd(bp, 1, s);
-    HIP_OK(hipMemsetAsync(bst, 0, bst_bytes, s));
+    bp.bst = bst + (size_t)(2 * r + 1) * bst_block;
     mtmc::launch_bwd_edge_upd(bp, 0, s);
     mtmc::launch_bwd_edge_upd(bp, 1, s);
 
@@ -126,12 +129,11 @@ extern "C" int32_t mtmc_mpn_backward(const mtmc_mpn_model* model, const mtmc_mpn
   {
     mtmc::BwdEncParams ep;
     ep.enc = enc_params(x); ep.attr = call->edge_attr; ep.n_edges = E; ep.e_total = (double)E; ep.g_e0 = g_e0;
-    ep.bst = bst; ep.d_attr = d_edge_attr;
+    ep.bst = bst + (size_t)(2 * L) * bst_block; ep.d_attr = d_edge_attr;
     ep.gr_w1 = const_cast<float*>(grads->enc_edge[0].weight); ep.gr_b1 = const_cast<float*>(grads->enc_edge[0].bias);
     ep.gr_g1 = const_cast<float*>(grads->enc_edge[0].gamma); ep.gr_bt1 = const_cast<float*>(grads->enc_edge[0].beta);
     ep.gr_w2 = const_cast<float*>(grads->enc_edge[1].weight); ep.gr_b2 = const_cast<float*>(grads->enc_edge[1].bias);
     ep.gr_g2 = const_cast<float*>(grads->enc_edge[1].gamma); ep.gr_bt2 = const_cast<float*>(grads->enc_edge[1].beta);
-    HIP_OK(hipMemsetAsync(bst, 0, bst_bytes, s));
     for (int pass = 0; pass < 3; ++pass) mtmc::launch_bwd_edge_enc(ep, pass, s);
   }
 
@@ -146,14 +148,14 @@ extern "C" int32_t mtmc_mpn_backward(const mtmc_mpn_model* model, const mtmc_mpn
     const int64_t npad = (N + 31) / 32 * 32;
     size_t maxd = 0;
     for (int l = 0; l < m->n_enc_layers; ++l) maxd = std::max(maxd, (size_t)std::max(m->enc_node[l].in_dim, m->enc_node[l].out_dim));
-    HIP_OK(zero(zeros, maxd));
     HIP_OK(hipMemcpyAsync(gA, g_h0, (size_t)N * 32 * sizeof(float), hipMemcpyDeviceToDevice, s));
     const mtmc::Drop nodrop = {0, 0, 1.f, 0};
     for (int l = m->n_enc_layers - 1; l >= 0; --l) {
       const mtmc_layer& Lr = m->enc_node[l];
       const int d = Lr.out_dim, in = Lr.in_dim;
-      double* sb = x.at<double>(lo.bst_n);
-      HIP_OK(hipMemsetAsync(sb, 0, (size_t)2 * d * sizeof(double), s));
+      size_t sb_off = 0;
+      for (int j = 0; j < l; ++j) sb_off += 2 * (size_t)m->enc_node[j].out_dim;
+      double* sb = x.at<double>(lo.bst_n) + sb_off;
       mtmc::BnBwdParams bb;
       bb.Y = x.at<float>(lo.Y[l]); bb.dA = gA; bb.rows = N; bb.dim = d;
       bb.stats_fwd = x.at<double>(lo.stat_enc_layer[l]); bb.stats_bwd = sb; bb.count = (double)N;
@@ -193,3 +195,21 @@ extern "C" int32_t mtmc_mpn_backward(const mtmc_mpn_model* model, const mtmc_mpn
   return MTMC_OK;
 }
 
+extern "C" int32_t mtmc_mpn_backward(const mtmc_mpn_model* model, const mtmc_mpn_call* call, const float* d_logits,
+                                     const float* d_h, const mtmc_mpn_model* grads, float* d_x, float* d_edge_attr) {
+  const float* steps[64];
+  int n_out = 0;
+  if (model && call && d_logits) {
+    n_out = std::min(model->num_class_steps, model->num_enc_steps);
+    if (n_out > 64) return fail(MTMC_E_ARG, "more than 64 classified steps");
+    for (int i = 0; i < n_out; ++i) steps[i] = d_logits + (size_t)i * call->n_edges * model->cls.out_dim;
+  }
+  return backward_impl(model, call, d_logits ? steps : nullptr, d_h, grads, nullptr, 0, d_x, d_edge_attr);
+}
+
+extern "C" int32_t mtmc_mpn_backward_steps(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
+                                           const float* const* d_logits_steps, const float* d_h,
+                                           const mtmc_mpn_model* grads, void* grads_flat, size_t grads_flat_bytes,
+                                           float* d_x, float* d_edge_attr) {
+  return backward_impl(model, call, d_logits_steps, d_h, grads, grads_flat, grads_flat_bytes, d_x, d_edge_attr);
+}

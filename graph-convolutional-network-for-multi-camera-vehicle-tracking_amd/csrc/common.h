@@ -68,6 +68,51 @@ __device__ __forceinline__ float wave_sum_f32(float v) {   // total in lane 63
   return v;
 }
 
+// dst[key*stride + j] += v[j] for every active lane, with lanes that carry the same key next to each other reduced
+// in the wave first: one DPP sum + NV atomics when the whole wave shares a key (the common case on row-sorted edge
+// lists, where per-lane atomics would all hit one address), otherwise a segmented scan and one atomic per run.
+// All 64 lanes must call (inactive lanes: active = false; their v is ignored).
+template <int NV>
+__device__ __forceinline__ void wave_run_atomic_add(const float (&vin)[NV], int key, bool active, float* dst,
+                                                    int64_t stride) {
+  const int lane = threadIdx.x & 63;
+  if (!active) key = -1;
+  float v[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) v[j] = active ? vin[j] : 0.f;
+  const int k0 = __builtin_amdgcn_readfirstlane(key);
+  if (__all(key == k0)) {
+    if (k0 < 0) return;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = wave_sum_f32(v[j]);
+    if (lane == kWaveSumLane) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) unsafeAtomicAdd(dst + (int64_t)k0 * stride + j, v[j]);
+    }
+    return;
+  }
+  const int prev = __shfl_up(key, 1, 64);
+  int flag = (lane == 0 || prev != key) ? 1 : 0;
+  const int next_head = __shfl_down(flag, 1, 64);
+  const bool tail = active && (lane == 63 || next_head != 0);
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int f_up = __shfl_up(flag, off, 64);
+    float u[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) u[j] = __shfl_up(v[j], off, 64);
+    if (lane >= off && !flag) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) v[j] += u[j];
+      flag = f_up;
+    }
+  }
+  if (tail) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) unsafeAtomicAdd(dst + (int64_t)key * stride + j, v[j]);
+  }
+}
+
 // dst[i] = sum over replicas of src[r*stride + i], i < n  (cooperative; caller synchronises afterwards)
 __device__ __forceinline__ void stat_gather(const double* src, int n, int stride, double* dst) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) {

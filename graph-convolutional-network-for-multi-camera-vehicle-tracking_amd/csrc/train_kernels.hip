@@ -174,7 +174,13 @@ __global__ __launch_bounds__(256) void bwd_edge_upd_kernel(BwdRoundParams p) {
   for (int i = 0; i < NV; ++i) acc[i] = 0;
   const int nin = p.f.reattach_edges ? 8 : 4;
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < p.f.n_edges; e += nthreads) {
+  for (int64_t e0w = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); e0w < p.f.n_edges; e0w += nthreads) {
+    // wave-uniform trip count: mode 1's run reduction is a cross-lane operation every lane has to reach together;
+    // lanes past the end compute on the last edge and are masked out of every side effect
+    const int64_t e_raw = e0w + (threadIdx.x & 63);
+    const bool active = e_raw < p.f.n_edges;
+    if (MODE == 0 && !active) continue;
+    const int64_t e = active ? e_raw : p.f.n_edges - 1;
     const float4 er4 = reinterpret_cast<const float4*>(p.f.e_out)[e];
     const float4 z4 = reinterpret_cast<const float4*>(p.f.e_buf)[e];
     const float er[4] = {er4.x, er4.y, er4.z, er4.w}, z1[4] = {z4.x, z4.y, z4.z, z4.w};
@@ -192,14 +198,17 @@ __global__ __launch_bounds__(256) void bwd_edge_upd_kernel(BwdRoundParams p) {
         for (int j = 0; j < 4; ++j) de[j] = fmaf(aw[j], d, de[j]);
       }
       if (p.d_logits) {
-        for (int c = 0; c < C; ++c) {
-          const float dl = p.d_logits[e * C + c];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            de[j] = fmaf(p.f.cls_w[c * 4 + j], dl, de[j]);
-            acc[8 + c * 4 + j] += (double)dl * er[j];
+        for (int c = 0; c < MTMC_MAX_CLASSES; ++c) {     // static indices into acc[]: it must stay in registers
+          if (c < C) {
+            const float dl = p.d_logits[e * C + c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              de[j] = fmaf(p.f.cls_w[c * 4 + j], dl, de[j]);
+              acc[8 + c * 4 + j] += (double)dl * er[j];
+            }
+            acc[24 + c] += dl;
           }
-          acc[24 + c] += dl;
         }
       }
       float g1[4];
@@ -215,16 +224,14 @@ __global__ __launch_bounds__(256) void bwd_edge_upd_kernel(BwdRoundParams p) {
       const float g1[4] = {g4.x, g4.y, g4.z, g4.w};
       float dz1[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        dz1[j] = p.f.ue_g[j] * sh.istd1[j] * (g1[j] - sh.mean_g[j] - zh[j] * sh.mean_gz[j]);
-        acc[j] += dz1[j];
-      }
+      for (int j = 0; j < 4; ++j) dz1[j] = p.f.ue_g[j] * sh.istd1[j] * (g1[j] - sh.mean_g[j] - zh[j] * sh.mean_gz[j]);
       const int r = p.f.row32[e], c = p.f.col32[e];
+      wave_run_atomic_add<4>(dz1, r, active, p.g_P, 8);   // rows come in long runs: reduce in the wave first
+      if (!active) continue;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        unsafeAtomicAdd(p.g_P + (int64_t)r * 8 + j, dz1[j]);
-        unsafeAtomicAdd(p.g_P + (int64_t)c * 8 + 4 + j, dz1[j]);
-      }
+      for (int j = 0; j < 4; ++j) acc[j] += dz1[j];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) unsafeAtomicAdd(p.g_P + (int64_t)c * 8 + 4 + j, dz1[j]);
       // the edge input of this round: [e0 | e_prev] (reattach) or e_prev, with e_prev = e0 in the first round
       float e0[4] = {0, 0, 0, 0}, ein[8];
       if (p.f.first_round || p.f.reattach_edges) {
@@ -243,15 +250,18 @@ __global__ __launch_bounds__(256) void bwd_edge_upd_kernel(BwdRoundParams p) {
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) { ein[j] = p.f.reattach_edges ? e0[j] : ep[j]; ein[4 + j] = ep[j]; }
-      float din[8];
-      for (int j = 0; j < nin; ++j) {
-        float s = 0.f;
+      float din[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          s = fmaf(p.f.ue_w[kk * p.f.ue_ld + p.f.ue_eoff + j], dz1[kk], s);
-          acc[4 + kk * 8 + j] += (double)dz1[kk] * ein[j];
+      for (int j = 0; j < 8; ++j) {                      // static indices into acc[] / din[] (registers, not scratch)
+        if (j < nin) {
+          float s = 0.f;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            s = fmaf(p.f.ue_w[kk * p.f.ue_ld + p.f.ue_eoff + j], dz1[kk], s);
+            acc[4 + kk * 8 + j] += (double)dz1[kk] * ein[j];
+          }
+          din[j] = s;
         }
-        din[j] = s;
       }
       // route d e_in: the e_prev part goes to the previous round (or to e0 in the first round), the e0 part to e0
       float d0[4] = {0, 0, 0, 0}, dp[4];

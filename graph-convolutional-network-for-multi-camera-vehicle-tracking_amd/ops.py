@@ -3,6 +3,8 @@
   scatter_add / scatter_mean / scatter_max   the call forms of the third-party `torch_scatter` op the
       reference aggregates with (`scatter_*(src, index, dim=0, dim_size=N)`, reference models/mpn.py:196-202)
   mlp_forward                                `MLP.forward` (reference models/mlp.py:32-33), eval mode
+  cross_entropy                              `F.cross_entropy(input, target, weight, reduction=...)` on the [E, C<=4]
+      edge logits, forward and backward fused (the training callers' loss, reference train.py:88-93, :109-142)
 
 All of them run HIP kernels through the C ABI; CPU tensors are refused.
 """
@@ -104,3 +106,54 @@ def mlp_forward(mlp, inp: torch.Tensor) -> torch.Tensor:
                 y = torch.relu_(y)
             a = y
     return a
+
+
+_REDUCTIONS = {"mean": 0, "sum": 1, "none": 2}
+
+
+class _CrossEntropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, weight, mode, ignore_index):
+        n, c = logits.shape
+        dev = logits.device
+        x = logits.contiguous()
+        sums = torch.empty(2 * _lib.STAT_REPLICAS, dtype=torch.float64, device=dev)
+        per = torch.empty(n, dtype=torch.float32, device=dev) if mode == 2 else None
+        loss = torch.empty((), dtype=torch.float32, device=dev) if mode != 2 else None
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().mtmc_cross_entropy_forward(
+                x.data_ptr(), target.data_ptr(), weight.data_ptr() if weight is not None else None, n, c, ignore_index,
+                mode, per.data_ptr() if per is not None else None, sums.data_ptr(),
+                loss.data_ptr() if loss is not None else None, _stream(dev)))
+        ctx.save_for_backward(x, target, weight, sums)
+        ctx.mode, ctx.ignore_index = mode, ignore_index
+        return per if mode == 2 else loss
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, target, weight, sums = ctx.saved_tensors
+        n, c = x.shape
+        dev = x.device
+        d = torch.empty_like(x)
+        g = grad.contiguous().float()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().mtmc_cross_entropy_backward(
+                x.data_ptr(), target.data_ptr(), weight.data_ptr() if weight is not None else None, n, c,
+                ctx.ignore_index, ctx.mode, g.data_ptr(), sums.data_ptr(), d.data_ptr(), _stream(dev)))
+        return d, None, None, None, None
+
+
+def cross_entropy(input, target, weight=None, reduction: str = "mean", ignore_index: int = -100):
+    """Drop-in for `torch.nn.functional.cross_entropy(input, target, weight=weight, reduction=reduction)` with class
+    indices as targets, for the [E, C<=4] float32 edge logits of the MPN."""
+    if not (input.is_cuda and target.is_cuda):
+        raise RuntimeError("mtmc_mpn.cross_entropy: tensors must be on a ROCm GPU (no CPU path)")
+    if input.dim() != 2 or input.dtype != torch.float32 or input.shape[1] > 4 or target.shape != input.shape[:1]:
+        raise NotImplementedError("mtmc_mpn.cross_entropy: input must be float32 [E, C<=4], target int64 [E]")
+    if reduction not in _REDUCTIONS:
+        raise ValueError(f"{reduction} is not a valid value for reduction")
+    if weight is not None:
+        weight = weight.to(device=input.device, dtype=torch.float32).contiguous()
+        if weight.numel() != input.shape[1]:
+            raise RuntimeError("mtmc_mpn.cross_entropy: weight must have one entry per class")
+    return _CrossEntropy.apply(input, target.contiguous().long(), weight, _REDUCTIONS[reduction], int(ignore_index))

@@ -173,6 +173,12 @@ int32_t mtmc_mpn_forward(const mtmc_mpn_model* model, const mtmc_mpn_call* call)
 size_t mtmc_mpn_train_workspace_bytes(const mtmc_mpn_model* model, int64_t n_nodes, int64_t n_edges);
 int32_t mtmc_mpn_backward(const mtmc_mpn_model* model, const mtmc_mpn_call* call, const float* d_logits,
                           const float* d_h, const mtmc_mpn_model* grads, float* d_x, float* d_edge_attr);
+/* The same with one gradient pointer per classified step (host array of min(Cs, L) device pointers, NULL entries =
+ * no gradient for that step; what torch.autograd hands over) and, optionally, the ONE buffer all gradient tensors
+ * of `grads` were carved from: it is cleared with a single memset instead of one per tensor. */
+int32_t mtmc_mpn_backward_steps(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
+                                const float* const* d_logits_steps, const float* d_h, const mtmc_mpn_model* grads,
+                                void* grads_flat, size_t grads_flat_bytes, float* d_x, float* d_edge_attr);
 int32_t mtmc_mpn_run_phase(const mtmc_mpn_model* model, const mtmc_mpn_call* call, int32_t phase, int32_t arg);
 
 /* out[dim_size, C] (fp32) <- scatter of src[E, C] by index[E] along dim 0; rows nobody writes are 0.
@@ -204,6 +210,21 @@ int32_t mtmc_build_graph(const float* feats, int64_t feat_row_stride, int64_t n_
                          const int64_t* block_off, int32_t n_cams, int64_t n_edges, const int64_t* node_labels,
                          float* x_out, int64_t* edge_index_out, float* edge_attr_out, float* edge_labels_out,
                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- the training callers' loss: F.cross_entropy / nn.CrossEntropyLoss(weight, reduction) on [n][n_classes<=4]
+ * logits (reference train.py:88-93, :109-142, :178-186).  mode 0 = mean, 1 = sum, 2 = none.
+ * forward: per_sample[i] = w[y_i] * (logsumexp(x_i) - x_i[y_i]) (NULL to skip); sums = f64[2*MTMC_STAT_REPLICAS]
+ * scratch, on return sums[0] = sum_i per_sample[i], sums[1] = sum_i w[y_i]; loss_out[0] = sums[0]/sums[1] (mean) or
+ * sums[0] (NULL to skip).  Rows with y_i == ignore_index count for nothing.
+ * backward: d_logits[i][c] = g_i * w[y_i] * (softmax(x_i)[c] - [c == y_i]) with g_i = grad[0]/sums[1] (mean, needs the
+ * forward's sums), grad[0] (sum) or grad[i] (none).  All pointers are device pointers. */
+#define MTMC_STAT_REPLICAS 16
+int32_t mtmc_cross_entropy_forward(const float* logits, const int64_t* labels, const float* weight, int64_t n,
+                                   int32_t n_classes, int64_t ignore_index, int32_t mode, float* per_sample,
+                                   double* sums, float* loss_out, void* stream);
+int32_t mtmc_cross_entropy_backward(const float* logits, const int64_t* labels, const float* weight, int64_t n,
+                                    int32_t n_classes, int64_t ignore_index, int32_t mode, const float* grad,
+                                    const double* sums, float* d_logits, void* stream);
 
 /* ---- post-processing of the last logits (replaces reference inference.py:475-489, post_processing
  * inference.py:70-169 and utils.py compute_SCC_and_Clusters :30-52, splitting :54-123, remove_edges_single_direction

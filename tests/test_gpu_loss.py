@@ -1,0 +1,58 @@
+"""mtmc_mpn.ops.cross_entropy (fused forward + backward) against torch.nn.functional.cross_entropy."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from mtmc_mpn import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("reduction", ["mean", "sum", "none"])
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("classes", [2, 3])
+def test_matches_torch(reduction, weighted, classes):
+    g = torch.Generator().manual_seed(classes * 10 + weighted)
+    n = 20011
+    x = (torch.randn(n, classes, generator=g) * 3).to(DEV)
+    y = torch.randint(0, classes, (n,), generator=g).to(DEV)
+    y[::97] = -100                                                  # ignore_index rows
+    w = (torch.rand(classes, generator=g) + 0.5).to(DEV) if weighted else None
+    xa, xb = x.clone().requires_grad_(True), x.clone().double().requires_grad_(True)
+    got = ops.cross_entropy(xa, y, weight=w, reduction=reduction)
+    want = F.cross_entropy(xb, y, weight=w.double() if weighted else None, reduction=reduction)
+    scale = max(1.0, float(want.abs().max()))
+    assert got.shape == want.shape
+    assert float((got.double() - want).abs().max()) <= 2e-6 * scale
+    up = torch.randn(want.shape, generator=g, dtype=torch.float64).to(DEV) if reduction == "none" else torch.tensor(1.7, device=DEV, dtype=torch.float64)
+    got.backward(up.float())
+    want.backward(up)
+    gs = max(1e-6, float(xb.grad.abs().max()))
+    assert float((xa.grad.double() - xb.grad).abs().max()) <= 2e-6 * gs
+
+
+def test_training_loss_on_module_outputs():
+    """The reference's weighted-CE branch (train.py:118-138) written with the fused op: same value and gradients."""
+    g = torch.Generator().manual_seed(3)
+    n = 5000
+    x = torch.randn(n, 2, generator=g).to(DEV)
+    y = (torch.rand(n, generator=g) < 0.02).long().to(DEV)
+    n1 = float(y.sum()); n0 = n - n1
+    w = torch.tensor([1.0, n0 / n1], device=DEV)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    per = F.cross_entropy(xb, y, reduction="none")                  # reference formulation, piece by piece
+    ref = (per * w[y]).sum() / w[y].sum()
+    got = ops.cross_entropy(xa, y, weight=w, reduction="mean")
+    assert abs(float(got) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    got.backward(); ref.backward()
+    assert float((xa.grad - xb.grad).abs().max()) <= 1e-6 * float(xb.grad.abs().max()) + 1e-9
+
+
+def test_errors():
+    with pytest.raises(RuntimeError, match="ROCm GPU"):
+        ops.cross_entropy(torch.zeros(4, 2), torch.zeros(4, dtype=torch.long))
+    with pytest.raises(NotImplementedError):
+        ops.cross_entropy(torch.zeros(4, 7, device=DEV), torch.zeros(4, dtype=torch.long, device=DEV))
+    with pytest.raises(ValueError):
+        ops.cross_entropy(torch.zeros(4, 2, device=DEV), torch.zeros(4, dtype=torch.long, device=DEV), reduction="avg")
