@@ -127,7 +127,7 @@ inline void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* l
     lo->bwd_zero = off;
     lo->bst = take((size_t)(2 * L + 1) * mtmc::kStatRep * kBwdStride * sizeof(double));   // per round: node, edge; + encoder
     lo->bst_n = take(bn_stats * sizeof(double));
-    lo->g_P = take((size_t)(L > 0 ? L : 1) * N * 8 * sizeof(float));      // per round
+    lo->g_P = take((size_t)(L > 0 ? L : 1) * 16 * N * 8 * sizeof(float)); // per round: [kGradRep = 16][N][8]
     lo->g_Q = take((size_t)(L > 0 ? L : 1) * N * 32 * sizeof(float));     // per round
     lo->zeros = take(maxd * sizeof(float));
     lo->g_h0 = take((size_t)N * 32 * sizeof(float));

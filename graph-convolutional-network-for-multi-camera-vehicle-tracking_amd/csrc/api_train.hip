@@ -97,7 +97,7 @@ static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
     const int step = r + 1;
     bp.d_logits = (d_logits_steps && step >= first_cls) ? d_logits_steps[step - first_cls] : nullptr;
     bp.g_dz2 = x.at<float>(lo.g_dz2);
-    bp.g_Q = x.at<float>(lo.g_Q) + (size_t)r * N * 32; bp.g_P = x.at<float>(lo.g_P) + (size_t)r * N * 8;
+    bp.g_Q = x.at<float>(lo.g_Q) + (size_t)r * N * 32; bp.g_P = x.at<float>(lo.g_P) + (size_t)r * mtmc::kGradRep * N * 8;
     bp.g_e = g_e[cur_e]; bp.g_e_prev = g_e[cur_e ^ 1]; bp.g_e0 = g_e0; bp.bst = bst + (size_t)(2 * r) * bst_block;
     bp.gr_un_w = const_cast<float*>(grads->upd_node.weight); bp.gr_un_b = const_cast<float*>(grads->upd_node.bias);
     bp.gr_un_g = const_cast<float*>(grads->upd_node.gamma); bp.gr_un_bt = const_cast<float*>(grads->upd_node.beta);

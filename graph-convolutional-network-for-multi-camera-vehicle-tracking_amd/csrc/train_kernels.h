@@ -4,6 +4,8 @@
 
 namespace mtmc {
 
+constexpr int kGradRep = 16;   // replicas of the dP accumulator (see bwd_edge_upd_kernel)
+
 constexpr int kBwdStrideD = 256;   // doubles per replica of the backward statistics scratch (api_internal.h: kBwdStride)
 
 struct BwdRoundParams {
@@ -14,7 +16,7 @@ struct BwdRoundParams {
   int* arg;                  // [N][32] max aggregation: edge index of the arg max per (node, channel)
   const float* d_logits;     // [E][C] gradient of this round's logits, or nullptr
   float* g_dz2;              // [E][32] scratch: gradient wrt the node-update pre-activation
-  float* g_Q; float* g_P;    // [N][32], [N][8] (zeroed by the host before the round)
+  float* g_Q; float* g_P;    // [N][32], [kGradRep][N][8] (zeroed by the host before the round)
   float* g_e;                // [E][4] in: gradient wrt e_r from later rounds; becomes g1 (mode 0 of the edge kernel)
   float* g_e_prev;           // [E][4] out: gradient wrt e_{r-1}
   float* g_e0;               // [E][4] accumulated gradient wrt the encoded edges

@@ -226,12 +226,15 @@ __global__ __launch_bounds__(256) void bwd_edge_upd_kernel(BwdRoundParams p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) dz1[j] = p.f.ue_g[j] * sh.istd1[j] * (g1[j] - sh.mean_g[j] - zh[j] * sh.mean_gz[j]);
       const int r = p.f.row32[e], c = p.f.col32[e];
-      wave_run_atomic_add<4>(dz1, r, active, p.g_P, 8);   // rows come in long runs: reduce in the wave first
+      // dP: ~E/N atomics land on every one of the N*8 addresses and same-address atomics serialise in L2 (measured
+      // 53 us of this 62 us kernel); kGradRep replicas by workgroup cut the chains, bwd_node_proj adds them up
+      float* gP = p.g_P + (size_t)(blockIdx.x % kGradRep) * p.f.n_nodes * 8;
+      wave_run_atomic_add<4>(dz1, r, active, gP, 8);      // rows come in long runs: reduce in the wave first
       if (!active) continue;
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] += dz1[j];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) unsafeAtomicAdd(p.g_P + (int64_t)c * 8 + 4 + j, dz1[j]);
+      for (int j = 0; j < 4; ++j) unsafeAtomicAdd(gP + (int64_t)c * 8 + 4 + j, dz1[j]);
       // the edge input of this round: [e0 | e_prev] (reattach) or e_prev, with e_prev = e0 in the first round
       float e0[4] = {0, 0, 0, 0}, ein[8];
       if (p.f.first_round || p.f.reattach_edges) {
@@ -338,7 +341,16 @@ __global__ __launch_bounds__(256) void bwd_node_proj_kernel(BwdProjParams p) {
     for (int i = threadIdx.x; i < 32 * 40; i += blockDim.x) {
       const int n = i / 40, j = i % 40;
       const int64_t node = node0 + n;
-      gs[n * 41 + j] = node < p.n_nodes ? (j < 8 ? p.g_P[node * 8 + j] : p.g_Q[node * kH + j - 8]) : 0.f;
+      float v = 0.f;
+      if (node < p.n_nodes) {
+        if (j < 8) {
+#pragma unroll
+          for (int rep = 0; rep < kGradRep; ++rep) v += p.g_P[(size_t)rep * p.n_nodes * 8 + node * 8 + j];
+        } else {
+          v = p.g_Q[node * kH + j - 8];
+        }
+      }
+      gs[n * 41 + j] = v;
     }
     __syncthreads();
     // d[h0|h][node][c] = sum_j g[node][j] * W_j[c]
