@@ -30,6 +30,7 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 struct Layout {
   mtmc_ws_layout pub;
   size_t row32, col32, e_buf[2], P, Q, slab, enc_aff, row_start, carry;
+  size_t amax;                                 // u32[1 + 2*MTMC_MAX_ENC_LAYERS]: |x|max, |W_l|max, |Y_l|max (zeroed)
   size_t Y[MTMC_MAX_ENC_LAYERS];
   size_t stat_enc_layer[MTMC_MAX_ENC_LAYERS];
   // training: every round keeps its own buffers (the workspace is the backward tape) + backward scratch
@@ -88,6 +89,7 @@ inline void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* l
   lo->pub.stat_round_off = take((size_t)(L > 0 ? L : 1) * mtmc::kRoundBlock * sizeof(double));
   lo->pub.deg_off = take((size_t)N * sizeof(int32_t));
   lo->pub.seg_off = take((size_t)N * 4 * sizeof(double));
+  lo->amax = take((size_t)(1 + 2 * MTMC_MAX_ENC_LAYERS) * sizeof(uint32_t));
   lo->pub.zero_bytes = off;
   lo->pub.deg_global_off = take((size_t)N * sizeof(int32_t));
   lo->pub.h0_off = take((size_t)N * 32 * sizeof(float));
@@ -271,13 +273,22 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
     case kPhPrep: {
       if (phase != kPhPrep && hipMemsetAsync(x.ws, 0, x.lo.pub.zero_bytes, s) != hipSuccess)
         return fail(MTMC_E_HIP, "hipMemsetAsync failed");
-      if (phase != kPhMemset && c->n_edges > 0) {
+      if (phase != kPhMemset) {
         mtmc::PrepParams p;
         p.row = c->row; p.col = c->col; p.idx_stride = c->idx_stride; p.attr = c->edge_attr; p.fe = m->enc_edge[0].in_dim;
         p.n_edges = c->n_edges; p.n_nodes = c->n_nodes;
         p.row32 = x.at<int>(x.lo.row32); p.col32 = x.at<int>(x.lo.col32); p.deg = x.at<int>(x.lo.pub.deg_off);
         p.flags = x.at<int>(x.lo.pub.flags_off); p.stat_attr = x.at<double>(x.lo.pub.stat_attr_off);
         p.row_start = x.at<int>(x.lo.row_start);
+        // operand |.|max values of the node encoder ride along (this rank's rows of x; every layer's weights)
+        unsigned* amax = x.at<unsigned>(x.lo.amax);
+        p.n_jobs = 0;
+        if (c->node_hi > c->node_lo) {
+          p.jobs[p.n_jobs++] = {c->x, c->node_hi - c->node_lo, m->enc_node[0].in_dim, c->x_row_stride, amax};
+          for (int l = 0; l < m->n_enc_layers; ++l)
+            p.jobs[p.n_jobs++] = {m->enc_node[l].weight, m->enc_node[l].out_dim, m->enc_node[l].in_dim,
+                                  m->enc_node[l].in_dim, amax + 1 + l};
+        }
         mtmc::launch_prep(p, s);
       }
       break;
@@ -304,6 +315,12 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
       g.count = (double)c->n_nodes; g.stats_out = x.at<double>(x.lo.stat_enc_layer[arg]);
       g.M = rows; g.K = Lr.in_dim; g.Nout = Lr.out_dim;
       g.drop_in = make_drop(x, m->dropout_enc); g.drop_stream = mtmc::kDropEncNode + arg - 1;
+      {
+        unsigned* amax = x.at<unsigned>(x.lo.amax);
+        g.amax_a = arg == 0 ? amax : amax + 1 + MTMC_MAX_ENC_LAYERS + (arg - 1);
+        g.amax_w = amax + 1 + arg;
+        g.amax_y = amax + 1 + MTMC_MAX_ENC_LAYERS + arg;
+      }
       {  // the slab was sized for N rows; a shard with fewer rows may plan a larger split
         int sk_full, sk_here;
         mtmc::gemm_plan(c->n_nodes, g.K, g.Nout, &sk_full);

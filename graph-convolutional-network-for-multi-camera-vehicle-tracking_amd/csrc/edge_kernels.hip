@@ -19,11 +19,31 @@ namespace mtmc {
 // ------------------------------------------------------------------------------------------------
 // prep
 // ------------------------------------------------------------------------------------------------
+__device__ void amax_jobs(const PrepParams& p, int block, int n_blocks) {
+  for (int j = 0; j < p.n_jobs; ++j) {
+    const AmaxJob job = p.jobs[j];
+    const int c4n = job.cols / 4;                       // cols is a multiple of 32 (check_model)
+    const int64_t total = job.rows * c4n;
+    float m = 0.f;
+    for (int64_t i = (int64_t)block * 256 + threadIdx.x; i < total; i += (int64_t)n_blocks * 256) {
+      const float4 v = *reinterpret_cast<const float4*>(job.ptr + (i / c4n) * job.ld + (i % c4n) * 4);
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(job.out, __float_as_uint(m));
+  }
+}
+
 __global__ __launch_bounds__(256) void prep_kernel(PrepParams p) {
+  if ((int)blockIdx.x >= p.n_edge_blocks) {             // passenger workgroups: operand scales of the node encoder
+    amax_jobs(p, blockIdx.x - p.n_edge_blocks, gridDim.x - p.n_edge_blocks);
+    return;
+  }
   __shared__ double red[5 * 4];
   double acc[5] = {0, 0, 0, 0, 0};
   const int lane = threadIdx.x & 63;
-  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  const int64_t nthreads = (int64_t)p.n_edge_blocks * blockDim.x;
   // whole waves iterate together so that the run-length logic sees 64 consecutive edges
   const int64_t e_end = ((p.n_edges + 63) / 64) * 64;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < e_end; e += nthreads) {
@@ -448,8 +468,15 @@ static inline int edge_grid(int64_t n_edges, int per_block) {
 constexpr int64_t kSmallEdges = 2048 * 256;
 static inline int pick_ept(int64_t n_edges) { return n_edges <= kSmallEdges ? 1 : 4; }
 
-void launch_prep(const PrepParams& p, hipStream_t s) {
-  hipLaunchKernelGGL(prep_kernel, dim3(edge_grid(p.n_edges, 256)), dim3(256), 0, s, p);
+void launch_prep(const PrepParams& p0, hipStream_t s) {
+  PrepParams p = p0;
+  p.n_edge_blocks = p.n_edges > 0 ? edge_grid(p.n_edges, 256) : 0;
+  int64_t f4 = 0;
+  for (int j = 0; j < p.n_jobs; ++j) f4 += p.jobs[j].rows * (p.jobs[j].cols / 4);
+  const int64_t want = (f4 + 4095) / 4096;              // ~16 float4 per lane
+  const int extra = p.n_jobs > 0 ? (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want)) : 0;
+  if (p.n_edge_blocks + extra == 0) return;
+  hipLaunchKernelGGL(prep_kernel, dim3(p.n_edge_blocks + extra), dim3(256), 0, s, p);
 }
 void launch_enc2(const EdgeEncParams& enc, const float* attr, int64_t n_edges, double e_total, double* stat_enc2,
                  hipStream_t s) {

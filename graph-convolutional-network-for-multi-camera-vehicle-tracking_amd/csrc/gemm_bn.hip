@@ -389,6 +389,277 @@ __global__ __launch_bounds__(256) void gemm_bn_bf16x6_kernel(GemmParams p, int t
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same layer on the fp16 matrix cores at fp32 accuracy with HALF the bf16x6 work: x = h1 + h2 in fp16 carries
+// 22 mantissa bits once the operand is scaled into fp16's normal range (exact power-of-two scales from absmax
+// values gathered on the way: mtmc::amax_kernel for x and the weights, the producing layer's epilogue for Y), the
+// 11x11-bit products are exact in the fp32 accumulator, and three of them (a1w1 + a1w2 + a2w1) leave a representation
+// error of <= 1e-7 |a||w| -- below the rounding error of a plain fp32 dot product of this length.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+constexpr int kAffChunk = 512;   // input-affine columns resident in LDS (keeps two 128x128x64 blocks per CU)
+
+template <int TM, int TN, int BK>
+__global__ __launch_bounds__(256) void gemm_bn_f16x3_kernel(GemmParams p, int tiles_m, int tiles_n) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int LDB = BK + 8;                         // 80 / 144-byte rows: conflict-free 16-byte fragment reads
+  constexpr int C4 = BK / 4, A4 = BM * C4 / 256, B4 = BN * C4 / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int PSA = BM * LDB, PSB = BN * LDB;       // piece strides
+  _Float16* As = reinterpret_cast<_Float16*>(smem);   // [2][PSA]
+  _Float16* Bs = As + 2 * PSA;                        // [2][PSB]
+  const int kc = p.K / p.split_k;
+  const int k_base = blockIdx.y * kc;
+  float* s_in = reinterpret_cast<float*>(Bs + 2 * PSB);
+  const int aff_n = kc < kAffChunk ? kc : kAffChunk;  // BatchNorm affine of the input: kAffChunk columns at a time
+  float* t_in = s_in + aff_n;
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tm_idx = (slot / tiles_n) * 8 + xcd, tn_idx = slot % tiles_n;
+  if (tm_idx >= tiles_m) return;
+  const int64_t m0 = (int64_t)tm_idx * BM;
+  const int n0 = tn_idx * BN;
+  const bool act = p.stats_in != nullptr;
+  // Power-of-two scales that put the largest |operand| at 2^14 (fp16: 2^15 max, full 22-bit two-piece precision
+  // down to 2^-3): exact to apply and to undo.  W: the layer's absmax; A: x's absmax (layer 0), or a bound on
+  // relu(bn(Y_prev)) from Y_prev's absmax and this block's K-slice of the BatchNorm affine.
+  float* sc = t_in + aff_n;                             // [4] scale of A, scale of W, 1 / (both)
+  float* wred = sc + 4;                                 // [8]
+  float ms = 0.f, mt = 0.f;
+  auto fill_affine = [&](int chunk) {                   // s_in/t_in <- columns [chunk*kAffChunk, +aff_n) of the slice
+    for (int kk = threadIdx.x; kk < aff_n; kk += 256) {
+      const int kq = k_base + chunk * kAffChunk + kk;
+      if (chunk * kAffChunk + kk < kc)
+        bn_affine(p.stats_in[kq], p.stats_in[p.K + kq], p.count, p.gamma_in[kq], p.beta_in[kq], s_in[kk], t_in[kk]);
+    }
+  };
+  if (act) {
+    for (int kk = threadIdx.x; kk < kc; kk += 256) {     // all of the slice once, for the bound on |relu(bn(.))|
+      float sv, tv;
+      bn_affine(p.stats_in[k_base + kk], p.stats_in[p.K + k_base + kk], p.count, p.gamma_in[k_base + kk],
+                p.beta_in[k_base + kk], sv, tv);
+      if (kk < aff_n) { s_in[kk] = sv; t_in[kk] = tv; }
+      ms = fmaxf(ms, fabsf(sv));
+      mt = fmaxf(mt, fabsf(tv));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      ms = fmaxf(ms, __shfl_xor(ms, off, 64));
+      mt = fmaxf(mt, __shfl_xor(mt, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { wred[threadIdx.x >> 6] = ms; wred[4 + (threadIdx.x >> 6)] = mt; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float bound = __uint_as_float(*p.amax_a);
+    if (act) {
+      const float s4 = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+      const float t4 = fmaxf(fmaxf(wred[4], wred[5]), fmaxf(wred[6], wred[7]));
+      bound = fmaf(bound, s4, t4) * (p.drop_in.on ? p.drop_in.inv_keep : 1.f);
+    }
+    int ea = 0, ew = 0;
+    const float aw = __uint_as_float(*p.amax_w);
+    if (bound > 0.f && bound < 3e38f) (void)frexpf(bound, &ea);
+    if (aw > 0.f && aw < 3e38f) (void)frexpf(aw, &ew);
+    sc[0] = ldexpf(1.f, 14 - ea);
+    sc[1] = ldexpf(1.f, 14 - ew);
+    sc[2] = ldexpf(1.f, ea + ew - 28);
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+
+  float4 ra[A4], rb[B4];
+  // Rows past M / columns past Nout are loaded from the last valid row instead of being zero-filled: they only feed
+  // accumulators the epilogue never stores, and unconditional loads keep the k-loop free of exec-mask branches.
+  const float* a_src[A4];
+  const float* b_src[B4];
+#pragma unroll
+  for (int i = 0; i < A4; ++i) {
+    const int f = threadIdx.x + i * 256, r = f / C4, c4 = f % C4;
+    const int64_t row = m0 + r < p.M ? m0 + r : p.M - 1;
+    a_src[i] = p.A + row * p.lda + k_base + c4 * 4;
+  }
+#pragma unroll
+  for (int i = 0; i < B4; ++i) {
+    const int f = threadIdx.x + i * 256, r = f / C4, c4 = f % C4;
+    const int n = n0 + r < p.Nout ? n0 + r : p.Nout - 1;
+    b_src[i] = p.W + (int64_t)n * p.K + k_base + c4 * 4;
+  }
+  auto load_tiles = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < A4; ++i) ra[i] = *reinterpret_cast<const float4*>(a_src[i] + kt * BK);
+#pragma unroll
+    for (int i = 0; i < B4; ++i) rb[i] = *reinterpret_cast<const float4*>(b_src[i] + kt * BK);
+  };
+  auto put = [&](_Float16* base, int piece_stride, int r, int c4, float4 v, float scale) {
+    typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
+    const float x0 = v.x * scale, x1 = v.y * scale, x2 = v.z * scale, x3 = v.w * scale;
+    // two-piece split with truncating conversions (v_cvt_pkrtz_f16_f32): h1 = rtz(x), h2 = rtz(x - h1); the
+    // residual x - h1 is exact, 22 mantissa bits are kept.  Deliberately NOT `(_Float16)x`: hipcc 7.2 lowers that
+    // to v_cvt_pk_f16_f32 / v_fma_mix{lo,hi}_f16 sequences which, with two or more of these workgroups resident on
+    // a CU, sporadically left zeros in the pieces written by lanes 48-63 (reproducer: tools/dbg_gemm.py)
+    const h2_t a01 = __builtin_amdgcn_cvt_pkrtz(x0, x1), a23 = __builtin_amdgcn_cvt_pkrtz(x2, x3);
+    const h2_t b01 = __builtin_amdgcn_cvt_pkrtz(x0 - (float)a01[0], x1 - (float)a01[1]);
+    const h2_t b23 = __builtin_amdgcn_cvt_pkrtz(x2 - (float)a23[0], x3 - (float)a23[1]);
+    uint2 q1, q2;
+    q1.x = __builtin_bit_cast(unsigned, a01); q1.y = __builtin_bit_cast(unsigned, a23);
+    q2.x = __builtin_bit_cast(unsigned, b01); q2.y = __builtin_bit_cast(unsigned, b23);
+    *reinterpret_cast<uint2*>(base + r * LDB + c4 * 4) = q1;
+    *reinterpret_cast<uint2*>(base + piece_stride + r * LDB + c4 * 4) = q2;
+  };
+  auto store_tiles = [&](int kt) {
+    const int k0 = kt * BK;
+    const float sa = sc[0], sw = sc[1];
+#pragma unroll
+    for (int i = 0; i < A4; ++i) {
+      const int f = threadIdx.x + i * 256, r = f / C4, c4 = f % C4;
+      float4 v = ra[i];
+      if (act) {
+        const float4 s = *reinterpret_cast<const float4*>(s_in + (k0 % kAffChunk) + c4 * 4);
+        const float4 t = *reinterpret_cast<const float4*>(t_in + (k0 % kAffChunk) + c4 * 4);
+        v.x = fmaxf(fmaf(v.x, s.x, t.x), 0.f);
+        v.y = fmaxf(fmaf(v.y, s.y, t.y), 0.f);
+        v.z = fmaxf(fmaf(v.z, s.z, t.z), 0.f);
+        v.w = fmaxf(fmaf(v.w, s.w, t.w), 0.f);
+        if (p.drop_in.on) {
+          const unsigned long long idx = (unsigned long long)(m0 + r) * p.K + k_base + k0 + c4 * 4;
+          v.x = drop_apply(p.drop_in, p.drop_stream, idx, v.x);
+          v.y = drop_apply(p.drop_in, p.drop_stream, idx + 1, v.y);
+          v.z = drop_apply(p.drop_in, p.drop_stream, idx + 2, v.z);
+          v.w = drop_apply(p.drop_in, p.drop_stream, idx + 3, v.w);
+        }
+      }
+      put(As, PSA, r, c4, v, sa);
+    }
+#pragma unroll
+    for (int i = 0; i < B4; ++i) {
+      const int f = threadIdx.x + i * 256, r = f / C4, c4 = f % C4;
+      put(Bs, PSB, r, c4, rb[i], sw);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = kc / BK;
+  load_tiles(0);
+  const int a_off = (wm * TM * 32 + (lane & 31)) * LDB + (lane >> 5) * 8;
+  const int b_off = (wn * TN * 32 + (lane & 31)) * LDB + (lane >> 5) * 8;
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    if (act && kt > 0 && (kt * BK) % kAffChunk == 0) {   // next kAffChunk columns of the input affine
+      fill_affine(kt * BK / kAffChunk);
+      __syncthreads();
+    }
+    store_tiles(kt);
+    __syncthreads();
+    if (kt + 1 < nk) load_tiles(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      f16x8 a[TM][2], b[TN][2];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) a[i][q] = *reinterpret_cast<const f16x8*>(As + q * PSA + a_off + i * 32 * LDB + ks * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) b[j][q] = *reinterpret_cast<const f16x8*>(Bs + q * PSB + b_off + j * 32 * LDB + ks * 16);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          // fp16 x fp16 products are exact in the fp32 accumulator; the dropped a2.w2 term is <= 2^-22 |a||w|
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+
+  const float inv = sc[2];
+  if (p.split_k > 1) {
+    float* slab = p.slab + (size_t)blockIdx.y * p.M * p.Nout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row < p.M && col < p.Nout) slab[row * p.Nout + col] = acc[i][j][r] * inv;
+        }
+    }
+    return;
+  }
+  __syncthreads();
+  double* colred = reinterpret_cast<double*>(smem);
+  float ymax = 0.f;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int cl = wn * TN * 32 + j * 32 + (lane & 31);
+    const int col = n0 + cl;
+    const float bias = col < p.Nout ? p.bias[col] : 0.f;
+    double cs = 0, cq = 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < p.M && col < p.Nout) {
+          const float y = fmaf(acc[i][j][r], inv, bias);
+          p.Y[row * p.ldy + col] = y;
+          ymax = fmaxf(ymax, fabsf(y));
+          cs += y;
+          cq += (double)y * y;
+        }
+      }
+    }
+    cs += __shfl_xor(cs, 32, 64);
+    cq += __shfl_xor(cq, 32, 64);
+    if (lane < 32) {
+      colred[(wm * 2 + 0) * BN + cl] = cs;
+      colred[(wm * 2 + 1) * BN + cl] = cq;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * BN; i += 256) {
+    const int which = i / BN, cl = i % BN, col = n0 + cl;
+    if (col < p.Nout && p.stats_out)
+      unsafeAtomicAdd(p.stats_out + which * p.Nout + col, colred[(0 * 2 + which) * BN + cl] + colred[(1 * 2 + which) * BN + cl]);
+  }
+  if (p.amax_y) {                                        // the next layer scales its A operand from this
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, off, 64));
+    if (lane == 0) atomicMax(p.amax_y, __float_as_uint(ymax));
+  }
+}
+
+template <int TM, int TN, int BK>
+static void launch_f16x3(const GemmParams& p, hipStream_t s) {
+  constexpr int BM = 64 * TM, BN = 64 * TN, LDB = BK + 8;
+  const int tiles_m = (int)((p.M + BM - 1) / BM), tiles_n = (p.Nout + BN - 1) / BN;
+  const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
+  const int kc = p.K / p.split_k;
+  size_t lds = (size_t)2 * (BM + BN) * LDB * 2 + (size_t)(2 * (kc < kAffChunk ? kc : kAffChunk) + 12) * sizeof(float);
+  const size_t epi = (size_t)4 * BN * sizeof(double);
+  if (lds < epi) lds = epi;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bn_f16x3_kernel<TM, TN, BK>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_bn_f16x3_kernel<TM, TN, BK>), dim3(grid, p.split_k), dim3(256), lds, s, p, tiles_m, tiles_n);
+}
+
 template <int TM, int TN, int BK>
 static void launch_bf16x6(const GemmParams& p, hipStream_t s) {
   constexpr int BM = 64 * TM, BN = 64 * TN, LDB = BK + 8;
@@ -419,6 +690,7 @@ __global__ __launch_bounds__(256) void combine_stats_kernel(GemmParams p) {
   const int64_t r0 = (int64_t)blockIdx.y * kCombRows;
   const size_t slice = (size_t)p.M * p.Nout;
   double cs = 0, cq = 0;
+  float ymax = 0.f;
   if (col < p.Nout) {
     const float bias = p.bias[col];
 #pragma unroll
@@ -432,10 +704,16 @@ __global__ __launch_bounds__(256) void combine_stats_kernel(GemmParams p) {
 #pragma unroll
         for (int z = 0; z < kMaxSplit; ++z) y += v[z];
         p.Y[row * p.ldy + col] = y;
+        ymax = fmaxf(ymax, fabsf(y));
         cs += y;
         cq += (double)y * y;
       }
     }
+  }
+  if (p.amax_y) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, off, 64));
+    if (cl == 0) atomicMax(p.amax_y, __float_as_uint(ymax));
   }
   red[rg * 64 + cl] = cs;
   red[256 + rg * 64 + cl] = cq;
@@ -521,7 +799,13 @@ int launch_gemm_bn(const GemmParams& p, hipStream_t s, int which) {
   q.split_k = (p.slab != nullptr) ? sk : 1;
   if (which & 1) {
     static const bool fp32_only = getenv("MTMC_GEMM_FP32") != nullptr;
-    if (cfg == 2 && !fp32_only) launch_bf16x6<2, 2, 32>(q, s);
+    static const bool no_f16 = getenv("MTMC_GEMM_NO_F16") != nullptr;
+    const bool f16 = p.amax_a && p.amax_w && !fp32_only && !no_f16;
+    if (cfg == 2 && f16 && p.K % 64 == 0) launch_f16x3<2, 2, 64>(q, s);
+    else if (cfg == 2 && f16) launch_f16x3<2, 2, 32>(q, s);
+    else if (cfg == 1 && f16 && (p.K / q.split_k) % 64 == 0) launch_f16x3<1, 1, 64>(q, s);
+    else if (cfg == 1 && f16) launch_f16x3<1, 1, 32>(q, s);
+    else if (cfg == 2 && !fp32_only) launch_bf16x6<2, 2, 32>(q, s);
     else if (cfg == 2) launch_cfg<2, 2, 32>(q, s);
     else if ((p.K / q.split_k) % 64 == 0) launch_cfg<1, 1, 64>(q, s);
     else launch_cfg<1, 1, 32>(q, s);

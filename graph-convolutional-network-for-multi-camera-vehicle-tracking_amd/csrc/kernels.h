@@ -5,7 +5,13 @@
 
 namespace mtmc {
 
+// |.|max of a [rows][cols] fp32 matrix (row stride ld), accumulated with atomicMax on the bit pattern: scales of the
+// fp16 two-piece node-encoder GEMM.  Done by extra workgroups of prep_kernel, i.e. without a launch of its own.
+struct AmaxJob { const float* ptr; int64_t rows; int cols; int64_t ld; unsigned* out; };
+
 struct PrepParams {
+  int n_edge_blocks, n_jobs;          // grid = n_edge_blocks + passenger blocks working through jobs[]
+  AmaxJob jobs[MTMC_MAX_ENC_LAYERS + 1];
   const int64_t* row; const int64_t* col; int64_t idx_stride;
   const float* attr; int fe;
   int64_t n_edges; int64_t n_nodes;
@@ -71,6 +77,10 @@ struct GemmParams {
   Drop drop_in; unsigned drop_stream;  // training: dropout applied with the input BatchNorm+ReLU
   float* slab;                       // [split_k][M][Nout] scratch for split-K partial tiles, or nullptr
   int split_k;                       // set by launch_gemm_bn
+  // fp16 two-piece path (gemm_bn_f16x3_kernel): |.|max bit patterns, device memory; nullptr = not available
+  const unsigned* amax_a = nullptr;  // of A's source: x itself (no stats_in) or the producing layer's raw Y
+  const unsigned* amax_w = nullptr;  // of W
+  unsigned* amax_y = nullptr;        // out (atomicMax): of this layer's raw Y
 };
 
 void launch_prep(const PrepParams& p, hipStream_t s);
