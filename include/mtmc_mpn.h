@@ -195,6 +195,12 @@ int32_t mtmc_scatter_max(const float* src, const int64_t* index, int64_t n_src, 
 int32_t mtmc_mlp_layer_forward(const mtmc_layer* layer, const float* x, int64_t x_row_stride, int64_t rows,
                                float* y, double* stats_scratch, void* stream);
 
+/* Diagnostics / unit tests: Y[M][N] = A[M][K] . W[N][K]^T + bias through the node encoder's GEMM dispatch exactly as the
+ * forward runs its first layer (operand scales gathered on the device, fp16 two-piece kernel where it applies);
+ * K a multiple of 32.  scratch: u32[4]; stats: f64[2*N] column sum / sum of squares of Y, or NULL. */
+int32_t mtmc_linear_raw(const float* A, int64_t lda, const float* W, const float* bias, float* Y, int64_t M, int32_t K,
+                        int32_t N, uint32_t* scratch, double* stats, void* stream);
+
 /* ---- graph construction (SURVEY.md 8(f)-1,2; replaces reference inference.py:402-456 / train.py:316-342) ----
  * feats [N][F] raw per-tracklet features -> x_out [N][F] (column-normalised like F.normalize(dim=0) if l2norm),
  * edge_index_out [E][2] int64 (row, col) in the reference's order (per camera, ascending: nodes of the camera x nodes
