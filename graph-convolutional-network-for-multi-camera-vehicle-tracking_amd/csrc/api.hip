@@ -148,24 +148,24 @@ int32_t mtmc_mlp_layer_forward(const mtmc_layer* layer, const float* x, int64_t 
 
 // Diagnostics / unit tests: Y[M][N] = A[M][K] . W[N][K]^T + bias through the node encoder's GEMM dispatch exactly as
 // the forward uses it for layer 0 (operand |.|max gathered by prep_kernel's passenger workgroups, fp16 two-piece
-// kernel where it applies).  scratch: u32[4], stats: f64[2*N] or NULL.
+// kernel where it applies).  scratch: u32[48], stats: f64[2*N] or NULL.
 int32_t mtmc_linear_raw(const float* A, int64_t lda, const float* W, const float* bias, float* Y, int64_t M, int32_t K,
                         int32_t N, uint32_t* scratch, double* stats, void* stream) {
   if (!A || !W || !bias || !Y || !scratch || M < 1 || K < 32 || K % 32 || N < 1) return fail(MTMC_E_ARG, "bad arguments");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(scratch, 0, 4 * sizeof(uint32_t), s) != hipSuccess) return fail(MTMC_E_HIP, "hipMemsetAsync failed");
+  if (hipMemsetAsync(scratch, 0, 3 * mtmc::kAmaxRep * sizeof(uint32_t), s) != hipSuccess) return fail(MTMC_E_HIP, "hipMemsetAsync failed");
   if (stats && hipMemsetAsync(stats, 0, 2 * (size_t)N * sizeof(double), s) != hipSuccess) return fail(MTMC_E_HIP, "hipMemsetAsync failed");
   mtmc::PrepParams p = {};
   p.n_edges = 0; p.n_jobs = 2;
-  p.jobs[0] = {A, M, K, lda, scratch};
-  p.jobs[1] = {W, N, K, K, scratch + 1};
+  p.jobs[0] = {A, M, K, lda, scratch, 0, 0};
+  p.jobs[1] = {W, N, K, K, scratch + mtmc::kAmaxRep, 0, 0};
   mtmc::launch_prep(p, s);
   mtmc::GemmParams g;
   g.A = A; g.lda = lda; g.W = W; g.bias = bias; g.Y = Y; g.ldy = N;
   g.stats_in = nullptr; g.gamma_in = nullptr; g.beta_in = nullptr; g.count = (double)M;
   g.stats_out = stats; g.M = M; g.K = K; g.Nout = N;
   g.slab = nullptr; g.split_k = 1; g.drop_in = {0, 0, 1.f, 0}; g.drop_stream = 0;
-  g.amax_a = scratch; g.amax_w = scratch + 1; g.amax_y = scratch + 2;
+  g.amax_a = scratch; g.amax_w = scratch + mtmc::kAmaxRep; g.amax_y = scratch + 2 * mtmc::kAmaxRep;
   if (mtmc::launch_gemm_bn(g, s) != MTMC_OK) return fail(MTMC_E_ARG, "unsupported shape");
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? MTMC_OK : fail(MTMC_E_HIP, "launch failed: %s", hipGetErrorString(e));

@@ -89,7 +89,7 @@ inline void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* l
   lo->pub.stat_round_off = take((size_t)(L > 0 ? L : 1) * mtmc::kRoundBlock * sizeof(double));
   lo->pub.deg_off = take((size_t)N * sizeof(int32_t));
   lo->pub.seg_off = take((size_t)N * 4 * sizeof(double));
-  lo->amax = take((size_t)(1 + 2 * MTMC_MAX_ENC_LAYERS) * sizeof(uint32_t));
+  lo->amax = take((size_t)(1 + 2 * MTMC_MAX_ENC_LAYERS) * mtmc::kAmaxRep * sizeof(uint32_t));
   lo->pub.zero_bytes = off;
   lo->pub.deg_global_off = take((size_t)N * sizeof(int32_t));
   lo->pub.h0_off = take((size_t)N * 32 * sizeof(float));
@@ -284,10 +284,10 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
         unsigned* amax = x.at<unsigned>(x.lo.amax);
         p.n_jobs = 0;
         if (c->node_hi > c->node_lo) {
-          p.jobs[p.n_jobs++] = {c->x, c->node_hi - c->node_lo, m->enc_node[0].in_dim, c->x_row_stride, amax};
+          p.jobs[p.n_jobs++] = {c->x, c->node_hi - c->node_lo, m->enc_node[0].in_dim, c->x_row_stride, amax, 0, 0};
           for (int l = 0; l < m->n_enc_layers; ++l)
             p.jobs[p.n_jobs++] = {m->enc_node[l].weight, m->enc_node[l].out_dim, m->enc_node[l].in_dim,
-                                  m->enc_node[l].in_dim, amax + 1 + l};
+                                  m->enc_node[l].in_dim, amax + (1 + l) * mtmc::kAmaxRep, 0, 0};
         }
         mtmc::launch_prep(p, s);
       }
@@ -317,9 +317,9 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
       g.drop_in = make_drop(x, m->dropout_enc); g.drop_stream = mtmc::kDropEncNode + arg - 1;
       {
         unsigned* amax = x.at<unsigned>(x.lo.amax);
-        g.amax_a = arg == 0 ? amax : amax + 1 + MTMC_MAX_ENC_LAYERS + (arg - 1);
-        g.amax_w = amax + 1 + arg;
-        g.amax_y = amax + 1 + MTMC_MAX_ENC_LAYERS + arg;
+        g.amax_a = arg == 0 ? amax : amax + (1 + MTMC_MAX_ENC_LAYERS + (arg - 1)) * mtmc::kAmaxRep;
+        g.amax_w = amax + (1 + arg) * mtmc::kAmaxRep;
+        g.amax_y = amax + (1 + MTMC_MAX_ENC_LAYERS + arg) * mtmc::kAmaxRep;
       }
       {  // the slab was sized for N rows; a shard with fewer rows may plan a larger split
         int sk_full, sk_here;

@@ -19,25 +19,33 @@ namespace mtmc {
 // ------------------------------------------------------------------------------------------------
 // prep
 // ------------------------------------------------------------------------------------------------
-__device__ void amax_jobs(const PrepParams& p, int block, int n_blocks) {
-  for (int j = 0; j < p.n_jobs; ++j) {
-    const AmaxJob job = p.jobs[j];
-    const int c4n = job.cols / 4;                       // cols is a multiple of 32 (check_model)
-    const int64_t total = job.rows * c4n;
-    float m = 0.f;
-    for (int64_t i = (int64_t)block * 256 + threadIdx.x; i < total; i += (int64_t)n_blocks * 256) {
-      const float4 v = *reinterpret_cast<const float4*>(job.ptr + (i / c4n) * job.ld + (i % c4n) * 4);
-      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-    }
+__device__ void amax_jobs(const PrepParams& p, int block) {
+  __shared__ float wmax[4];
+  int j = 0;
+  while (j + 1 < p.n_jobs && block >= p.jobs[j + 1].block0) ++j;      // every passenger workgroup serves ONE job
+  const AmaxJob job = p.jobs[j];
+  const int c4n = job.cols / 4;                         // cols is a multiple of 32 (check_model)
+  const int64_t total = job.rows * c4n;
+  const bool dense = job.ld == job.cols;                // weights and contiguous x: no row arithmetic
+  float m = 0.f;
+  for (int64_t i = (int64_t)(block - job.block0) * 256 + threadIdx.x; i < total; i += (int64_t)job.n_blocks * 256) {
+    const float* src = dense ? job.ptr + i * 4 : job.ptr + (i / c4n) * job.ld + (i % c4n) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(src);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(job.out, __float_as_uint(m));
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float b = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    if (b > 0.f) atomicMax(job.out + (block % kAmaxRep), __float_as_uint(b));
   }
 }
 
 __global__ __launch_bounds__(256) void prep_kernel(PrepParams p) {
   if ((int)blockIdx.x >= p.n_edge_blocks) {             // passenger workgroups: operand scales of the node encoder
-    amax_jobs(p, blockIdx.x - p.n_edge_blocks, gridDim.x - p.n_edge_blocks);
+    amax_jobs(p, blockIdx.x - p.n_edge_blocks);
     return;
   }
   __shared__ double red[5 * 4];
@@ -471,10 +479,13 @@ static inline int pick_ept(int64_t n_edges) { return n_edges <= kSmallEdges ? 1 
 void launch_prep(const PrepParams& p0, hipStream_t s) {
   PrepParams p = p0;
   p.n_edge_blocks = p.n_edges > 0 ? edge_grid(p.n_edges, 256) : 0;
-  int64_t f4 = 0;
-  for (int j = 0; j < p.n_jobs; ++j) f4 += p.jobs[j].rows * (p.jobs[j].cols / 4);
-  const int64_t want = (f4 + 4095) / 4096;              // ~16 float4 per lane
-  const int extra = p.n_jobs > 0 ? (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want)) : 0;
+  int extra = 0;
+  for (int j = 0; j < p.n_jobs; ++j) {                  // ~16 float4 per lane, at most 256 workgroups per operand
+    const int64_t f4 = p.jobs[j].rows * (p.jobs[j].cols / 4), want = (f4 + 4095) / 4096;
+    p.jobs[j].block0 = extra;
+    p.jobs[j].n_blocks = (int)(want < 1 ? 1 : (want > 256 ? 256 : want));
+    extra += p.jobs[j].n_blocks;
+  }
   if (p.n_edge_blocks + extra == 0) return;
   hipLaunchKernelGGL(prep_kernel, dim3(p.n_edge_blocks + extra), dim3(256), 0, s, p);
 }

@@ -452,14 +452,17 @@ __global__ __launch_bounds__(256) void gemm_bn_f16x3_kernel(GemmParams p, int ti
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    float bound = __uint_as_float(*p.amax_a);
+    unsigned ua = 0, uw = 0;                              // kAmaxRep replicas each (atomicMax chains kept short)
+#pragma unroll
+    for (int r = 0; r < kAmaxRep; ++r) { ua = max(ua, p.amax_a[r]); uw = max(uw, p.amax_w[r]); }
+    float bound = __uint_as_float(ua);
     if (act) {
       const float s4 = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
       const float t4 = fmaxf(fmaxf(wred[4], wred[5]), fmaxf(wred[6], wred[7]));
       bound = fmaf(bound, s4, t4) * (p.drop_in.on ? p.drop_in.inv_keep : 1.f);
     }
     int ea = 0, ew = 0;
-    const float aw = __uint_as_float(*p.amax_w);
+    const float aw = __uint_as_float(uw);
     if (bound > 0.f && bound < 3e38f) (void)frexpf(bound, &ea);
     if (aw > 0.f && aw < 3e38f) (void)frexpf(aw, &ew);
     sc[0] = ldexpf(1.f, 14 - ea);
@@ -638,7 +641,13 @@ __global__ __launch_bounds__(256) void gemm_bn_f16x3_kernel(GemmParams p, int ti
   if (p.amax_y) {                                        // the next layer scales its A operand from this
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, off, 64));
-    if (lane == 0) atomicMax(p.amax_y, __float_as_uint(ymax));
+    __syncthreads();                                     // colred consumed; reuse its first words
+    float* wmax = reinterpret_cast<float*>(smem);
+    if (lane == 0) wmax[wid] = ymax;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      atomicMax(p.amax_y + (blockIdx.x % kAmaxRep),
+                __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
   }
 }
 
@@ -710,14 +719,18 @@ __global__ __launch_bounds__(256) void combine_stats_kernel(GemmParams p) {
       }
     }
   }
+  __shared__ float wmax[4];
   if (p.amax_y) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, off, 64));
-    if (cl == 0) atomicMax(p.amax_y, __float_as_uint(ymax));
+    if (cl == 0) wmax[rg] = ymax;
   }
   red[rg * 64 + cl] = cs;
   red[256 + rg * 64 + cl] = cq;
   __syncthreads();
+  if (p.amax_y && threadIdx.x == 0)
+    atomicMax(p.amax_y + ((blockIdx.x + blockIdx.y) % kAmaxRep),
+              __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
   if (threadIdx.x < 128 && p.stats_out) {
     const int which = threadIdx.x >> 6, c = blockIdx.x * 64 + (threadIdx.x & 63);
     if (c < p.Nout) {

@@ -7,7 +7,8 @@ namespace mtmc {
 
 // |.|max of a [rows][cols] fp32 matrix (row stride ld), accumulated with atomicMax on the bit pattern: scales of the
 // fp16 two-piece node-encoder GEMM.  Done by extra workgroups of prep_kernel, i.e. without a launch of its own.
-struct AmaxJob { const float* ptr; int64_t rows; int cols; int64_t ld; unsigned* out; };
+constexpr int kAmaxRep = 16;   // replicas of every |.|max word: same-address atomics serialise in L2
+struct AmaxJob { const float* ptr; int64_t rows; int cols; int64_t ld; unsigned* out; int block0, n_blocks; };   // block range: set by launch_prep
 
 struct PrepParams {
   int n_edge_blocks, n_jobs;          // grid = n_edge_blocks + passenger blocks working through jobs[]
@@ -77,7 +78,8 @@ struct GemmParams {
   Drop drop_in; unsigned drop_stream;  // training: dropout applied with the input BatchNorm+ReLU
   float* slab;                       // [split_k][M][Nout] scratch for split-K partial tiles, or nullptr
   int split_k;                       // set by launch_gemm_bn
-  // fp16 two-piece path (gemm_bn_f16x3_kernel): |.|max bit patterns, device memory; nullptr = not available
+  // fp16 two-piece path (gemm_bn_f16x3_kernel): |.|max bit patterns, u32[kAmaxRep] each (take the max), device
+  // memory; nullptr = not available
   const unsigned* amax_a = nullptr;  // of A's source: x itself (no stats_in) or the producing layer's raw Y
   const unsigned* amax_w = nullptr;  // of W
   unsigned* amax_y = nullptr;        // out (atomicMax): of this layer's raw Y

@@ -197,7 +197,7 @@ int32_t mtmc_mlp_layer_forward(const mtmc_layer* layer, const float* x, int64_t 
 
 /* Diagnostics / unit tests: Y[M][N] = A[M][K] . W[N][K]^T + bias through the node encoder's GEMM dispatch exactly as the
  * forward runs its first layer (operand scales gathered on the device, fp16 two-piece kernel where it applies);
- * K a multiple of 32.  scratch: u32[4]; stats: f64[2*N] column sum / sum of squares of Y, or NULL. */
+ * K a multiple of 32.  scratch: u32[48]; stats: f64[2*N] column sum / sum of squares of Y, or NULL. */
 int32_t mtmc_linear_raw(const float* A, int64_t lda, const float* W, const float* bias, float* Y, int64_t M, int32_t K,
                         int32_t N, uint32_t* scratch, double* stats, void* stream);
 

@@ -13,7 +13,7 @@ def run(A, W, b, with_stats=True):
     M, K = A.shape
     N = W.shape[0]
     Y = torch.empty(M, N, device=DEV)
-    scr = torch.zeros(4, dtype=torch.int32, device=DEV)
+    scr = torch.zeros(48, dtype=torch.int32, device=DEV)
     st = torch.empty(2 * N, dtype=torch.float64, device=DEV) if with_stats else None
     _lib.check(lib.mtmc_linear_raw(A.data_ptr(), A.stride(0), W.data_ptr(), b.data_ptr(), Y.data_ptr(), M, K, N,
                                    scr.data_ptr(), st.data_ptr() if st is not None else None,

@@ -19,7 +19,7 @@ A = torch.randn(M, K, generator=g).cuda()
 W = ((torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5).cuda()
 b = torch.randn(N, generator=g).cuda() * 0.01
 Y = torch.empty(M, N, device="cuda")
-scr = torch.zeros(4, dtype=torch.int32, device="cuda")
+scr = torch.zeros(48, dtype=torch.int32, device="cuda")
 ref = (A.double() @ W.double().t() + b.double())
 for rep in range(3):
     Y.zero_()
