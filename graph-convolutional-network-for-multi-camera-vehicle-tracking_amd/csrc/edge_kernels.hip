@@ -28,11 +28,18 @@ __device__ void amax_jobs(const PrepParams& p, int block) {
   const int64_t total = job.rows * c4n;
   const bool dense = job.ld == job.cols;                // weights and contiguous x: no row arithmetic
   float m = 0.f;
-  for (int64_t i = (int64_t)(block - job.block0) * 256 + threadIdx.x; i < total; i += (int64_t)job.n_blocks * 256) {
+  const int64_t stride = (int64_t)job.n_blocks * 256;
+  auto at = [&](int64_t i) {
     const float* src = dense ? job.ptr + i * 4 : job.ptr + (i / c4n) * job.ld + (i % c4n) * 4;
-    const float4 v = *reinterpret_cast<const float4*>(src);
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    return *reinterpret_cast<const float4*>(src);
+  };
+  auto fold = [&](const float4 v) { m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w))); };
+  int64_t i = (int64_t)(block - job.block0) * 256 + threadIdx.x;
+  for (; i + 3 * stride < total; i += 4 * stride) {       // four independent 16-byte loads in flight per lane
+    const float4 v0 = at(i), v1 = at(i + stride), v2 = at(i + 2 * stride), v3 = at(i + 3 * stride);
+    fold(v0); fold(v1); fold(v2); fold(v3);
   }
+  for (; i < total; i += stride) fold(at(i));
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
   if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
@@ -480,10 +487,10 @@ void launch_prep(const PrepParams& p0, hipStream_t s) {
   PrepParams p = p0;
   p.n_edge_blocks = p.n_edges > 0 ? edge_grid(p.n_edges, 256) : 0;
   int extra = 0;
-  for (int j = 0; j < p.n_jobs; ++j) {                  // ~16 float4 per lane, at most 256 workgroups per operand
+  for (int j = 0; j < p.n_jobs; ++j) {                  // ~16 float4 per lane, at most 2048 workgroups per operand
     const int64_t f4 = p.jobs[j].rows * (p.jobs[j].cols / 4), want = (f4 + 4095) / 4096;
     p.jobs[j].block0 = extra;
-    p.jobs[j].n_blocks = (int)(want < 1 ? 1 : (want > 256 ? 256 : want));
+    p.jobs[j].n_blocks = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
     extra += p.jobs[j].n_blocks;
   }
   if (p.n_edge_blocks + extra == 0) return;
