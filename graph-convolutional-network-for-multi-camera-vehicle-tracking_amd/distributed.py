@@ -73,9 +73,32 @@ class ShardedForward:
     def _max(self, t):
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
 
-    def __call__(self, x_local, node_range, edge_index_local, edge_attr_local, n_edges_total):
+    def _gather_rows(self, h, row_ranges, rank, world):
+        """Every rank holds COMPLETE rows [lo_r, hi_r) of h (row-snapped shards of a row-sorted list): exchange them
+        with one all-gather (half the bytes of the all-reduce they make unnecessary), padded to the longest range."""
+        longest = max(hi - lo for lo, hi in row_ranges)
+        if longest == 0:
+            return
+        lo, hi = row_ranges[rank]
+        send = h.new_zeros((longest, h.shape[1]))
+        send[:hi - lo] = h[lo:hi]
+        if dist.get_backend(self.group) == "nccl":
+            recv = h.new_empty((world * longest, h.shape[1]))
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+            parts = recv.view(world, longest, h.shape[1])
+        else:
+            parts = [torch.empty_like(send) for _ in range(world)]
+            dist.all_gather(parts, send, group=self.group)
+        for r, (rlo, rhi) in enumerate(row_ranges):
+            if r != rank and rhi > rlo:
+                h[rlo:rhi] = parts[r][:rhi - rlo]
+
+    def __call__(self, x_local, node_range, edge_index_local, edge_attr_local, n_edges_total, row_ranges=None):
         """x_local: rows [node_range[0], node_range[1]) of x; node_range = (lo, hi, N).
-        edge_index_local / edge_attr_local: this rank's edge slice (global node ids)."""
+        edge_index_local / edge_attr_local: this rank's edge slice (global node ids).
+        row_ranges: per rank, the node range [lo, hi) that contains ALL source rows of its edge slice and no source
+        row of any other rank's (see `row_ranges_of`); when given, the node states are exchanged by all-gather
+        instead of all-reduce."""
         be, spec = self.backend, self.spec
         world = dist.get_world_size(self.group)
         rank = dist.get_rank(self.group)
@@ -119,16 +142,41 @@ class ShardedForward:
                 self._sum(be.region(prep, "round_z2", arg))
             elif ph == _lib.PH_ROUND_C:
                 h = be.region(prep, "agg", arg)
-                (self._max if spec.agg == "max" else self._sum)(h)
+                if row_ranges is not None:
+                    self._gather_rows(h, row_ranges, rank, world)
+                else:
+                    (self._max if spec.agg == "max" else self._sum)(h)
         return be.outputs(prep)
 
 
-def sharded_forward(module, x_local, node_range, edge_index_local, edge_attr_local, n_edges_total, group=None):
+def row_ranges_of(edge_index_local, group=None):
+    """[lo, hi) of the source rows in every rank's edge slice, or None if the slices are not row-disjoint (then the
+    node states must be all-reduced).  One tiny all-gather; call it once per graph, not per forward."""
+    world = dist.get_world_size(group)
+    row = edge_index_local[0]
+    mine = torch.tensor([int(row.min()), int(row.max()) + 1] if row.numel() else [0, 0], dtype=torch.int64, device=row.device)
+    if dist.get_backend(group) == "nccl":
+        allr = torch.empty(2 * world, dtype=torch.int64, device=row.device)
+        dist.all_gather_into_tensor(allr, mine, group=group)
+        allr = allr.view(world, 2).tolist()
+    else:
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        allr = [p.tolist() for p in parts]
+    ranges = [(int(a), int(b)) for a, b in allr]
+    live = sorted(r for r in ranges if r[1] > r[0])
+    if any(a[1] > b[0] for a, b in zip(live, live[1:])):
+        return None
+    return ranges
+
+
+def sharded_forward(module, x_local, node_range, edge_index_local, edge_attr_local, n_edges_total, group=None,
+                    row_ranges=None):
     """Convenience wrapper: one edge-partitioned forward of a (HIP-backed) MOTMPNet on this rank's shard.
     Returns ({'classified_edges': [local logits]}, h) with h replicated on every rank."""
     from . import engine
     if module._engine is None:
         module._engine = engine.ForwardEngine(module)
     logits, h = ShardedForward(module._engine, module.spec, group)(x_local, node_range, edge_index_local,
-                                                                  edge_attr_local, n_edges_total)
+                                                                  edge_attr_local, n_edges_total, row_ranges)
     return {"classified_edges": logits}, h

@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case_name, snap, out_dir):
+def _worker(rank, world, port, case_name, snap, out_dir, gather=False):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from cpu_phase_backend import CpuPhaseBackend
@@ -34,16 +34,20 @@ def _worker(rank, world, port, case_name, snap, out_dir):
         lo, hi = mdist.even_ranges(n, world)[rank]
         elo, ehi = mdist.edge_ranges(d.edge_index[0], e, world, snap_to_rows=snap)[rank]
         fwd = mdist.ShardedForward(CpuPhaseBackend(sd, m.spec), m.spec)
+        rr = None
+        if gather:
+            rr = mdist.row_ranges_of(d.edge_index[:, elo:ehi])
+            assert (rr is not None) == snap, "row-disjoint shards expected exactly for snapped boundaries"
         with torch.no_grad():
-            logits, h = fwd(d.x[lo:hi], (lo, hi, n), d.edge_index[:, elo:ehi], d.edge_attr[elo:ehi], e)
+            logits, h = fwd(d.x[lo:hi], (lo, hi, n), d.edge_index[:, elo:ehi], d.edge_attr[elo:ehi], e, rr)
         torch.save({"elo": elo, "ehi": ehi, "logits": [l.clone() for l in logits], "h": h.clone()},
                    os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
 
-def _run(case_name, world, snap, tmp_path):
-    mp.spawn(_worker, args=(world, _free_port(), case_name, snap, str(tmp_path)), nprocs=world, join=True)
+def _run(case_name, world, snap, tmp_path, gather=False):
+    mp.spawn(_worker, args=(world, _free_port(), case_name, snap, str(tmp_path), gather), nprocs=world, join=True)
     c = Case(case_name)
     parts = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt")) for r in range(world)]
     assert parts[0]["elo"] == 0 and parts[-1]["ehi"] == c.meta["E"]
@@ -85,6 +89,15 @@ def test_single_rank_cpu_backend_matches_golden():
 ])
 def test_sharded_forward_over_gloo(name, world, snap, tmp_path):
     _run(name, world, snap, tmp_path)
+
+
+@pytest.mark.parametrize("name,world,snap", [
+    ("g5_reattach_both_s02", 2, True),      # row-sorted + snapped: complete rows per rank -> all-gather of node states
+    ("g4_s02_L3", 3, True),                 # three ranks, uneven row ranges (padded gather)
+    ("g5_max", 2, False),                   # unsorted rows: row_ranges_of() says no, falls back to all-reduce
+])
+def test_row_complete_shards_use_all_gather(name, world, snap, tmp_path):
+    _run(name, world, snap, tmp_path, gather=True)
 
 
 def test_ranges():
