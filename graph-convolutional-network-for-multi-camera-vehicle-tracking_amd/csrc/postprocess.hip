@@ -26,8 +26,8 @@ namespace mtmc {
 constexpr int kPpChunk = 1024;            // edges per block in the wide kernels (256 lanes x 4)
 constexpr int kPpThreads = 1024;          // the graph kernel's workgroup
 constexpr int kPpLdsNodes = 2048;         // LDS-resident graph state up to this many nodes ...
-constexpr int kPpLdsEdges = 16384;        // ... and this many active edges
-constexpr int kPpNodeArrays = 9;          // rowptr, label, t0..t6
+constexpr int kPpLdsEdges = 8192;         // ... and this many active edges
+constexpr int kPpNodeArrays = 13;         // rowptr, label, t0..t6, component records (size, tree key, sequence, free ids)
 constexpr unsigned kDead = 0x80000000u;
 
 struct PpParams {
@@ -42,6 +42,7 @@ struct PpParams {
   // workspace
   int* hdr; int* block_count; int* a_idx; int* a_u; int* a_v; float* a_p; int* a_slot; unsigned char* alive;
   unsigned char* mark; int* g_node; unsigned* g_csr; int* g_flags; int* b_idx; int* b_u; int* b_v; float* b_p; int64_t cap;
+  int* g_wcc; int* g_dirty;                // [N] each: weakly connected component of a node, per-component dirty flag
 };
 
 __device__ __forceinline__ float softmax_p1(float l0, float l1) {
@@ -151,6 +152,7 @@ struct PpGraph {
   int* rowptr;     // [N+1] CSR over ALL compacted active edges, rows in ascending active id (= edge order)
   int* label;      // [N]   cluster number of the node's component (output numbering)
   int* t0; int* t1; int* t2; int* t3; int* t4; int* t5; int* t6;   // [N] each, phase-dependent (see uses)
+  int* csize; int* ctree; int* cseq; int* freel;                  // [N] each: component records of the splitting loop
   unsigned* csr;   // [A]   target node | kDead
   int n, a, cams;
 };
@@ -369,6 +371,135 @@ __device__ int pp_scc(const PpParams& p, const PpGraph& g, bool nodes_in_lds, bo
   return n_comp + n_iso;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Splitting loop without a full renumbering per iteration.  The loop only needs (a) the first over-sized set in the
+// reference's numbering and (b) the set that carries a given number after an edge was dropped.  The numbering is
+// "size, then networkx emission order"; emission order is "depth-first trees in order of their source's first
+// appearance in the active edge list, components within a tree in finish order".  Dropping an edge changes trees
+// only inside the weakly connected component (WCC) it belonged to, and positions in the edge list never move, so
+// every component keeps the key (size, first position of its tree's source, sequence within its walk); lane 0
+// re-walks the dirty WCCs alone and the numbers asked for are found by counting smaller keys.
+// ------------------------------------------------------------------------------------------------
+template <typename IP, typename UP>
+__device__ void pp_walk_inc(IP rowptr, IP pre, IP low, IP comp, IP cursor, IP dstack, IP sstack, UP csr, IP src, int n_src,
+                            IP csize, IP ctree, IP cseq, IP freel, int* n_free, int* n_ids) {
+  int counter = 0, seq = 0, stop = 0, nf = *n_free, ni = *n_ids;
+  for (int i = 0; i < n_src; ++i) {
+    const int source = src[i];
+    if (pre[source] != 0) continue;
+    const int tree_key = low[source];                    // unvisited: still the node's first position in the edge list
+    int dtop = 0;
+    dstack[dtop++] = source;
+    pre[source] = low[source] = ++counter;
+    sstack[stop++] = source;
+    while (dtop) {
+      const int v = dstack[dtop - 1];
+      const int end = rowptr[v + 1];
+      int c = cursor[v], lv = low[v];
+      int child = -1;
+      while (c < end) {
+        const unsigned t = csr[c++];
+        if (t & kDead) continue;
+        const int pt = pre[t];
+        if (pt == 0) { child = (int)t; break; }
+        if (comp[t] < 0) lv = min(lv, pt);
+      }
+      cursor[v] = c;
+      low[v] = lv;
+      if (child >= 0) {
+        dstack[dtop++] = child;
+        pre[child] = low[child] = ++counter;
+        sstack[stop++] = child;
+        continue;
+      }
+      --dtop;
+      if (dtop) {
+        const int par = dstack[dtop - 1];
+        if (lv < low[par]) low[par] = lv;
+      }
+      if (lv == pre[v]) {
+        const int id = nf > 0 ? freel[--nf] : ni++;
+        int w, cnt = 0;
+        do { w = sstack[--stop]; comp[w] = id; ++cnt; } while (w != v);
+        csize[id] = cnt; ctree[id] = tree_key; cseq[id] = seq++;
+      }
+    }
+  }
+  *n_free = nf; *n_ids = ni;
+}
+
+__device__ void pp_wcc(const PpParams& p, const PpGraph& g) {
+  for (int n = threadIdx.x; n < g.n; n += blockDim.x) p.g_wcc[n] = n;
+  __syncthreads();
+  for (;;) {
+    int changed = 0;
+    for (int k = threadIdx.x; k < g.a; k += blockDim.x) {
+      if (!p.alive[k]) continue;
+      const int u = p.a_u[k], v = p.a_v[k];
+      const int a = p.g_wcc[u], b = p.g_wcc[v];
+      if (a < b) { atomicMin(&p.g_wcc[v], a); changed = 1; }
+      else if (b < a) { atomicMin(&p.g_wcc[u], b); changed = 1; }
+    }
+    if (!__syncthreads_or(changed)) break;
+  }
+  // pointer jumping to the component minimum (labels only ever decrease towards it)
+  for (;;) {
+    int changed = 0;
+    for (int n = threadIdx.x; n < g.n; n += blockDim.x) {
+      const int w = p.g_wcc[n], ww = p.g_wcc[w];
+      if (ww != w) { p.g_wcc[n] = ww; changed = 1; }
+    }
+    if (!__syncthreads_or(changed)) break;
+  }
+}
+
+// Re-walk the dirty WCCs.  s_cnt: {free ids, ids in use (high-water mark)} in shared memory.
+__device__ void pp_inc_walk(const PpParams& p, const PpGraph& g, bool nodes_in_lds, bool csr_in_lds, int* s_cnt, int* sh) {
+  int* pre = g.t0; int* low = g.t1; int* comp = g.t2; int* cursor = g.t3; int* dstack = g.t4; int* sstack = g.t5;
+  int* src = g.t6;
+  for (int n = threadIdx.x; n < g.n; n += blockDim.x) {
+    if (!p.g_dirty[p.g_wcc[n]]) continue;
+    const int id = comp[n];
+    if (id >= 0 && atomicExch(&g.csize[id], 0) > 0) g.freel[atomicAdd(&s_cnt[0], 1)] = id;
+    pre[n] = 0; comp[n] = -1; cursor[n] = g.rowptr[n]; low[n] = 0x7fffffff;
+  }
+  for (int i = threadIdx.x; i < 2 * g.a; i += blockDim.x) p.g_flags[i] = 0;
+  __syncthreads();
+  for (int k = threadIdx.x; k < g.a; k += blockDim.x) {
+    if (!p.alive[k] || !p.g_dirty[p.g_wcc[p.a_u[k]]]) continue;
+    atomicMin(&low[p.a_u[k]], 2 * k);
+    atomicMin(&low[p.a_v[k]], 2 * k + 1);
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < g.n; n += blockDim.x)
+    if (p.g_dirty[p.g_wcc[n]] && low[n] != 0x7fffffff) p.g_flags[low[n]] = 1;
+  __syncthreads();
+  const int n_src = block_exclusive_scan(p.g_flags, 2 * (int64_t)g.a, sh);
+  for (int n = threadIdx.x; n < g.n; n += blockDim.x)
+    if (p.g_dirty[p.g_wcc[n]] && low[n] != 0x7fffffff) src[p.g_flags[low[n]]] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const long long t_begin = wall_clock64();
+    if (nodes_in_lds && csr_in_lds)
+      pp_walk_inc((LdsIntPtr)g.rowptr, (LdsIntPtr)pre, (LdsIntPtr)low, (LdsIntPtr)comp, (LdsIntPtr)cursor,
+                  (LdsIntPtr)dstack, (LdsIntPtr)sstack, (LdsUintPtr)g.csr, (LdsIntPtr)src, n_src,
+                  (LdsIntPtr)g.csize, (LdsIntPtr)g.ctree, (LdsIntPtr)g.cseq, (LdsIntPtr)g.freel, &s_cnt[0], &s_cnt[1]);
+    else
+      pp_walk_inc(g.rowptr, pre, low, comp, cursor, dstack, sstack, g.csr, src, n_src, g.csize, g.ctree, g.cseq,
+                  g.freel, &s_cnt[0], &s_cnt[1]);
+    p.hdr[2] += (int)(wall_clock64() - t_begin);
+  }
+  __syncthreads();
+}
+
+// key(a) < key(b) in the reference's numbering: size, then tree source position, then sequence within the walk
+__device__ __forceinline__ bool pp_key_less(const PpGraph& g, int a, int b) {
+  if (g.csize[a] != g.csize[b]) return g.csize[a] < g.csize[b];
+  if (g.ctree[a] != g.ctree[b]) return g.ctree[a] < g.ctree[b];
+  return g.cseq[a] < g.cseq[b];
+}
+
 // Drop the dead edges from the active arrays (stable) once the cut / prune stages are over: the walks of the
 // splitting loop then step over ~A_alive instead of A_in slots.  Dead edges get their prediction cleared here.
 __device__ int pp_compact_alive(const PpParams& p, const PpGraph& g, int* sh) {
@@ -397,7 +528,6 @@ __global__ __launch_bounds__(kPpThreads) void pp_graph_kernel(PpParams p, int ld
   extern __shared__ __attribute__((aligned(16))) int lds[];
   __shared__ int sh[kPpThreads / 64 + 1];
   __shared__ unsigned s_min;
-  __shared__ int s_lab;
   if (p.hdr[1]) {                                        // capacity exceeded: report, leave predictions = argmax
     if (threadIdx.x == 0) p.info[3] = 1;
     return;
@@ -409,6 +539,8 @@ __global__ __launch_bounds__(kPpThreads) void pp_graph_kernel(PpParams p, int ld
   g.rowptr = node_base; g.label = node_base + npad;
   g.t0 = node_base + 2 * npad; g.t1 = node_base + 3 * npad; g.t2 = node_base + 4 * npad; g.t3 = node_base + 5 * npad;
   g.t4 = node_base + 6 * npad; g.t5 = node_base + 7 * npad; g.t6 = node_base + 8 * npad;
+  g.csize = node_base + 9 * npad; g.ctree = node_base + 10 * npad; g.cseq = node_base + 11 * npad;
+  g.freel = node_base + 12 * npad;
   unsigned* lds_csr = reinterpret_cast<unsigned*>(lds + (lds_nodes ? kPpNodeArrays * npad : 0));
   bool csr_in_lds = g.a <= kPpLdsEdges;
   g.csr = csr_in_lds ? lds_csr : p.g_csr;
@@ -425,40 +557,87 @@ __global__ __launch_bounds__(kPpThreads) void pp_graph_kernel(PpParams p, int ld
     g.csr = csr_in_lds ? lds_csr : p.g_csr;
     pp_build_csr(p, g, sh);
   }
-  int n_sets = pp_scc(p, g, lds_nodes != 0, csr_in_lds, sh);
-  ++walks;
   if (splitting) {
-    // utils.py:54-123, tail recursion unrolled: pick the first over-sized label; drop every edge whose probability
-    // equals the minimum over the active edges touching that cluster; renumber; stay on the SAME label number while
-    // the set now carrying it is over-sized (reference quirk), else pick again
-    const int* lsize = g.t5;
+    // utils.py:54-123, tail recursion unrolled: pick the first over-sized set of the numbering; drop every edge whose
+    // probability equals the minimum over the active edges touching it; stay on the SAME NUMBER while the set that
+    // carries it after the renumbering is over-sized (reference quirk), else pick again
+    __shared__ int s_cnt[2], s_i[4];
+    __shared__ unsigned long long s_key;
+    int* over = g.t4;                                    // list of over-sized components (free outside the walks)
+    if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+    pp_wcc(p, g);
+    for (int n = threadIdx.x; n < g.n; n += blockDim.x) { p.g_dirty[n] = 1; g.t2[n] = -1; g.csize[n] = 0; }
+    __syncthreads();
+    pp_inc_walk(p, g, lds_nodes != 0, csr_in_lds, s_cnt, sh);
+    ++walks;
     for (;;) {
-      if (threadIdx.x == 0) s_lab = 0x7fffffff;
+      // first over-sized set = smallest key among the components with more than num_cameras nodes
+      if (threadIdx.x == 0) { s_i[0] = 0x7fffffff; s_key = ~0ull; s_i[1] = -1; s_i[2] = 0; }
       __syncthreads();
-      for (int l = threadIdx.x; l < n_sets; l += blockDim.x)
-        if (lsize[l] > g.cams) atomicMin(&s_lab, l);
+      const int n_ids = s_cnt[1];
+      for (int c = threadIdx.x; c < n_ids; c += blockDim.x)
+        if (g.csize[c] > g.cams) atomicMin(&s_i[0], g.csize[c]);
       __syncthreads();
-      const int lab = s_lab;
-      if (lab == 0x7fffffff) break;
+      const int min_size = s_i[0];
+      if (min_size == 0x7fffffff) break;
+      for (int c = threadIdx.x; c < n_ids; c += blockDim.x)
+        if (g.csize[c] == min_size)
+          atomicMin(&s_key, ((unsigned long long)(unsigned)g.ctree[c] << 32) | (unsigned)g.cseq[c]);
+      __syncthreads();
+      for (int c = threadIdx.x; c < n_ids; c += blockDim.x)
+        if (g.csize[c] == min_size && (((unsigned long long)(unsigned)g.ctree[c] << 32) | (unsigned)g.cseq[c]) == s_key)
+          s_i[1] = c;
+      __syncthreads();
+      int cur = s_i[1];
+      for (int c = threadIdx.x; c < n_ids; c += blockDim.x)      // its number = how many components precede it
+        if (g.csize[c] > 0 && pp_key_less(g, c, cur)) atomicAdd(&s_i[2], 1);
+      __syncthreads();
+      const int lab = s_i[2];
       for (;;) {
         if (threadIdx.x == 0) s_min = 0xffffffffu;
+        for (int n = threadIdx.x; n < g.n; n += blockDim.x) p.g_dirty[n] = 0;
         __syncthreads();
         for (int i = threadIdx.x; i < g.a; i += blockDim.x)
-          if (p.alive[i] && (g.label[p.a_u[i]] == lab || g.label[p.a_v[i]] == lab))
+          if (p.alive[i] && (g.t2[p.a_u[i]] == cur || g.t2[p.a_v[i]] == cur))
             atomicMin(&s_min, __float_as_uint(p.a_p[i]));
         __syncthreads();
         const unsigned mn = s_min;
         if (mn == 0xffffffffu) { status = 2; break; }    // cannot happen for a real component; never spin on it
         for (int i = threadIdx.x; i < g.a; i += blockDim.x)
-          if (p.alive[i] && __float_as_uint(p.a_p[i]) == mn) pp_kill(p, g, i);
+          if (p.alive[i] && __float_as_uint(p.a_p[i]) == mn) {
+            pp_kill(p, g, i);
+            p.g_dirty[p.g_wcc[p.a_u[i]]] = 1;
+          }
         __syncthreads();
-        n_sets = pp_scc(p, g, lds_nodes != 0, csr_in_lds, sh);
+        pp_inc_walk(p, g, lds_nodes != 0, csr_in_lds, s_cnt, sh);
         ++walks; ++split_iters;
-        if (!(lsize[lab] > g.cams)) break;
+        // which over-sized component carries number `lab` now?  (one wave per candidate counts the smaller keys)
+        if (threadIdx.x == 0) { s_i[3] = 0; s_i[1] = -1; }
+        __syncthreads();
+        const int ids_now = s_cnt[1];
+        for (int c = threadIdx.x; c < ids_now; c += blockDim.x)
+          if (g.csize[c] > g.cams) over[atomicAdd(&s_i[3], 1)] = c;
+        __syncthreads();
+        const int n_over = s_i[3], lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+        for (int o = wave; o < n_over; o += n_waves) {
+          const int id = over[o];
+          int cnt = 0;
+          for (int c = lane; c < ids_now; c += 64)
+            if (g.csize[c] > 0 && pp_key_less(g, c, id)) ++cnt;
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+          if (lane == 0 && cnt == lab) s_i[1] = id;
+        }
+        __syncthreads();
+        cur = s_i[1];
+        __syncthreads();
+        if (cur < 0) break;
       }
       if (status) break;
     }
   }
+  const int n_sets = pp_scc(p, g, lds_nodes != 0, csr_in_lds, sh);     // the reference's final numbering
+  ++walks;
   // outputs
   int alive_cnt = 0;
   for (int i = threadIdx.x; i < g.a; i += blockDim.x) {
@@ -477,7 +656,7 @@ __global__ __launch_bounds__(kPpThreads) void pp_graph_kernel(PpParams p, int ld
 }
 
 // ------------------------------------------------------------------------------------------------
-struct PpLayout { size_t hdr, block_count, a_idx, a_u, a_v, a_p, a_slot, alive, mark, g_node, g_csr, g_flags, b_idx, b_u, b_v, b_p, total; };
+struct PpLayout { size_t hdr, block_count, a_idx, a_u, a_v, a_p, a_slot, alive, mark, g_node, g_csr, g_flags, b_idx, b_u, b_v, b_p, g_wcc, g_dirty, total; };
 
 static PpLayout pp_layout(int64_t n_nodes, int64_t n_edges, int64_t cap) {
   PpLayout lo;
@@ -493,6 +672,7 @@ static PpLayout pp_layout(int64_t n_nodes, int64_t n_edges, int64_t cap) {
   lo.g_csr = take((size_t)cap * 4);
   lo.g_flags = take((size_t)cap * 8);
   lo.b_idx = take((size_t)cap * 4); lo.b_u = take((size_t)cap * 4); lo.b_v = take((size_t)cap * 4); lo.b_p = take((size_t)cap * 4);
+  lo.g_wcc = take((size_t)(n_nodes + 4) * 4); lo.g_dirty = take((size_t)(n_nodes + 4) * 4);
   lo.total = off;
   return lo;
 }
@@ -522,6 +702,7 @@ int launch_postprocess(const float* logits, const int64_t* row, const int64_t* c
   p.g_flags = reinterpret_cast<int*>(ws + lo.g_flags); p.b_idx = reinterpret_cast<int*>(ws + lo.b_idx);
   p.b_u = reinterpret_cast<int*>(ws + lo.b_u); p.b_v = reinterpret_cast<int*>(ws + lo.b_v);
   p.b_p = reinterpret_cast<float*>(ws + lo.b_p);
+  p.g_wcc = reinterpret_cast<int*>(ws + lo.g_wcc); p.g_dirty = reinterpret_cast<int*>(ws + lo.g_dirty);
   const int nb = (int)((n_edges + kPpChunk - 1) / kPpChunk);
   if (nb > 0) hipLaunchKernelGGL(pp_classify_kernel, dim3(nb), dim3(256), 0, s, p);
   hipLaunchKernelGGL(pp_scan_kernel, dim3(1), dim3(1024), 0, s, p, nb);
