@@ -303,3 +303,21 @@ def test_deterministic_mode_is_bitwise_repeatable_and_correct():
         assert (h1.cpu().double() - c.h(f64=True)).abs().max().item() <= 1e-4 * scale
         if name == "g4_s02_L3":                # globally row-sorted: the fixed-order path is taken
             assert torch.equal(h1, h2)
+
+
+def test_forked_edge_encoder_flag():
+    """MTMC_F_FORK: the edge encoder's statistics pass on a side stream beside the node-encoder GEMMs; same results."""
+    import ctypes as C
+    from mtmc_mpn import _lib, engine
+    c = Case("g4_s02_L3")
+    m, g = c.model().cuda().eval(), to_gpu(c.graph())
+    eng = engine.ForwardEngine(m)
+    with torch.no_grad():
+        prep = eng.prepare(g.x, g.edge_index, g.edge_attr)
+        eng.set_flags(prep, _lib.F_FORK)
+        for _ in range(2):
+            _lib.check(eng.lib.mtmc_mpn_forward(C.byref(prep.model), C.byref(prep.call)))
+        torch.cuda.synchronize()
+        logits, h = eng.outputs(prep)
+    assert (logits[0].cpu()[c.sub_idx] - c.logits(0)).abs().max().item() <= LOGIT_TOL
+    assert (h.cpu().double() - c.h(f64=True)).abs().max().item() <= 1e-4 * max(1.0, c.h(f64=True).abs().max().item())
