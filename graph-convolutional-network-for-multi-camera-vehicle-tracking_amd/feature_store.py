@@ -134,8 +134,11 @@ class FeatureStore:
                   pin: bool = False) -> torch.Tensor:
         """[N, F] float32 on `device` in ONE host-to-device copy (whole scene), or the given tracklets in the given
         order (gathered on the host first, still one copy)."""
+        import warnings
         if cams is None:
-            host = torch.from_numpy(np.ascontiguousarray(self.feats))
+            with warnings.catch_warnings():                 # read-only mapping: the tensor is only ever copied from
+                warnings.simplefilter("ignore", UserWarning)
+                host = torch.from_numpy(np.ascontiguousarray(self.feats))
         else:
             host = torch.from_numpy(self.feats[self.rows(cams, ids)])
         if pin and torch.cuda.is_available():
