@@ -791,7 +791,8 @@ int gemm_plan(int64_t M, int K, int Nout, int* split_k) {
   const int64_t tiles = ((M + 63) / 64) * ((Nout + 63) / 64);
   int s = 1;
   while (s < kMaxSplit && tiles * (s * 2) <= 1024 && K % (s * 2 * BK) == 0 && K / (s * 2) >= 64) s *= 2;
-  if (tiles < 256) *split_k = s;
+  // K <= 128: two k-tiles at most -- a slice per block saves nothing and costs the combine launch (measured, S02)
+  if (tiles < 256 && K > 128) *split_k = s;
   return 1;
 }
 
