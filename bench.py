@@ -219,6 +219,22 @@ def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
     data = make_workload(name, device)
     n, e = data.x.shape[0], data.edge_index.shape[1]
     sec = time_forward(model, data, steps, warmup)
+    launch_mode, eager_ms, replay_ms = "eager launches", sec * 1e3, None
+    if e <= 2_000_000 and not os.environ.get("MTMC_NO_GRAPH"):
+        # few-edge graphs: ~25 launches per forward can cost the host more than the forward costs the GPU; the same
+        # forward replayed from a HIP graph (model.capture) is immune to that -- report the faster way of launching it
+        with torch.no_grad():
+            replay = model.capture(data)
+            for _ in range(warmup):
+                replay()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                replay()
+            torch.cuda.synchronize(device)
+            replay_ms = (time.perf_counter() - t0) / steps * 1e3
+        if replay_ms < eager_ms:
+            sec, launch_mode = replay_ms * 1e-3, "HIP graph replay (model.capture)"
     seq, ms = time_phases(model, data, phase_iters)
     spec = model.spec
     # dominant kernel = the kernel NAME with the largest summed time (all its launches in a step, the same
@@ -265,6 +281,7 @@ def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
         phases[k] = phases.get(k, 0.0) + t
     res = {"workload": name, "description": desc, "N": n, "E": e, "L": L, "Cs": cs,
            "value": e / sec, "ms_per_step": sec * 1e3, "edge_rounds_per_s": e * L / sec,
+           "launch": {"mode": launch_mode, "eager_ms": eager_ms, "graph_replay_ms": replay_ms},
            "roofline": roofline,
            "forward_algorithmic": {"bytes": b_fwd, "GBps": b_fwd / sec / 1e9, "frac_of_hbm_peak": b_fwd / sec / 1e9 / HBM_PEAK_GBS,
                                    "note": "SURVEY 8(d) reference-formulation bytes / whole-forward time"},
@@ -410,7 +427,7 @@ def main():
             "dtype": "f32", "data": "synthetic (seeded features on the reference's S02 ground-truth topology; random-init weights)",
             "config": {"workload": f"{name}: {res['description']}, L={res['L']}, Cs={res['Cs']}, eval forward",
                        "N": res["N"], "E": res["E"], "parallelism": "1 GPU"},
-            "roofline": res["roofline"], "cpu_baseline": res.get("cpu_baseline"),
+            "roofline": res["roofline"], "cpu_baseline": res.get("cpu_baseline"), "launch": res["launch"],
             "forward_algorithmic": res["forward_algorithmic"], "edge_rounds_per_s": res["edge_rounds_per_s"],
             "phase_ms": res["phase_ms"]}
     if args.workload == "auto" and not args.no_stress:

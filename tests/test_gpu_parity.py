@@ -321,3 +321,24 @@ def test_forked_edge_encoder_flag():
         logits, h = eng.outputs(prep)
     assert (logits[0].cpu()[c.sub_idx] - c.logits(0)).abs().max().item() <= LOGIT_TOL
     assert (h.cpu().double() - c.h(f64=True)).abs().max().item() <= 1e-4 * max(1.0, c.h(f64=True).abs().max().item())
+
+
+def test_captured_forward_replays():
+    """model.capture(data): a HIP-graph replay gives the eager results, follows in-place input and weight changes."""
+    c = Case("g4_s02_L3")
+    m, g = c.model().cuda().eval(), to_gpu(c.graph())
+    with torch.no_grad():
+        eager, eager_h = m(g)
+        e0 = eager["classified_edges"][0].clone()
+        replay = m.capture(g)
+        out, h = replay()
+        assert (out["classified_edges"][0] - e0).abs().max().item() <= 2e-6
+        g.edge_attr.mul_(1.5)                              # new input values, same buffers
+        want, _ = m(g)
+        w0 = want["classified_edges"][0].clone()
+        out2, _ = replay()
+        assert (out2["classified_edges"][0] - w0).abs().max().item() <= 2e-6
+        assert (w0 - e0).abs().max().item() > 1e-4         # and it did change
+    m.train()
+    with pytest.raises(RuntimeError):
+        m.capture(g)
