@@ -29,6 +29,7 @@ constexpr int kPpLdsNodes = 2048;         // LDS-resident graph state up to this
 constexpr int kPpLdsEdges = 8192;         // ... and this many active edges
 constexpr int kPpNodeArrays = 13;         // rowptr, label, t0..t6, component records (size, tree key, sequence, free ids)
 constexpr unsigned kDead = 0x80000000u;
+constexpr int kPpMaxSplitIters = 1 << 18;  // splitting iterations before giving up (status 3); real runs need tens
 
 struct PpParams {
   const float* logits;                    // [E][2] or nullptr (then prob1/pred are inputs)
@@ -611,6 +612,7 @@ __global__ __launch_bounds__(kPpThreads) void pp_graph_kernel(PpParams p, int ld
         __syncthreads();
         pp_inc_walk(p, g, lds_nodes != 0, csr_in_lds, s_cnt, sh);
         ++walks; ++split_iters;
+        if (split_iters >= kPpMaxSplitIters) { status = 3; break; }   // a resident workgroup must not run unbounded
         // which over-sized component carries number `lab` now?  (one wave per candidate counts the smaller keys)
         if (threadIdx.x == 0) { s_i[3] = 0; s_i[1] = -1; }
         __syncthreads();

@@ -14,7 +14,8 @@ from . import _lib
 
 CUTTING, PRUNING, SPLITTING = 1, 2, 4
 _STATUS = {1: "more active edges than max_active: predictions left at argmax",
-           2: "over-sized cluster without an active edge"}
+           2: "over-sized cluster without an active edge",
+           3: "splitting did not finish within 262144 iterations (predictions hold the state reached)"}
 
 
 def _flag(v) -> bool:
