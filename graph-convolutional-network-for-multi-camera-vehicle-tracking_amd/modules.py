@@ -133,21 +133,28 @@ class MOTMPNet(nn.Module):
         CPU time than the forward takes on the GPU; weights may change between replays (they are read in place)."""
         if self.training:
             raise RuntimeError("mtmc_mpn: capture() is for eval-mode inference")
+        from . import engine
+        if self._engine is None:
+            self._engine = engine.ForwardEngine(self)
         dev = data.x.device
         with torch.no_grad():
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):                 # warm-up outside the capture: lazy library / workspace setup
+            with torch.cuda.stream(side):                 # warm-up outside the capture: lazy library setup
                 self.forward(data)
             torch.cuda.current_stream(dev).wait_stream(side)
+            before = dict(self._engine._ws)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = self.forward(data)
+            # the workspace the captured kernels write to must live exactly as long as the graph: take it out of the
+            # engine's per-stream cache (a later, larger forward on that stream would otherwise replace and free it)
+            held = [self._engine._ws.pop(k) for k in list(self._engine._ws) if before.get(k) is not self._engine._ws[k]]
 
         def replay():
             graph.replay()
             return out
-        replay.graph = graph
+        replay.graph, replay.workspaces = graph, held
         return replay
 
     def forward(self, data):
