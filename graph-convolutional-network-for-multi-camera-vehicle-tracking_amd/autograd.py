@@ -70,6 +70,15 @@ class _MpnFunction(torch.autograd.Function):
                 C.byref(prep.model), C.byref(prep.call), steps, dh.data_ptr() if dh is not None else None,
                 C.byref(grads_struct), flat.data_ptr(), flat.numel() * 4,
                 dx.data_ptr() if dx is not None else None, dattr.data_ptr() if dattr is not None else None))
+        if engine.spec.num_enc_steps == 0:        # the update MLPs took no part: None, as autograd gives the reference
+            dead = set()
+            for (slot, _), lin, bn, _ in layers:
+                if slot in ("upd_edge", "upd_node"):
+                    dead |= {id(lin.weight), id(lin.bias)} | ({id(bn.weight), id(bn.bias)} if bn is not None else set())
+            order = []
+            for _, lin, bn, _ in layers:
+                order += [lin.weight, lin.bias] + ([bn.weight, bn.bias] if bn is not None else [])
+            grad_tensors = [None if id(p) in dead else g for p, g in zip(order, grad_tensors)]
         return (None, None, None, dx, None, dattr) + tuple(grad_tensors)
 
 
@@ -84,8 +93,6 @@ def _ordered_params(engine):
 
 
 def forward_with_tape(engine, x, edge_index, edge_attr, training):
-    if engine.spec.num_enc_steps < 1:
-        raise NotImplementedError("mtmc_mpn: backward with num_enc_steps == 0 is not implemented")
     seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if training else 0    # follows torch.manual_seed
     out = _MpnFunction.apply(engine, bool(training), seed, x, edge_index, edge_attr, *_ordered_params(engine))
     return list(out[:-1]), out[-1]

@@ -36,7 +36,6 @@ static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
   if (int rc = check_grads(model, grads)) return rc;
   const mtmc_mpn_model* m = model;
   const int L = m->num_enc_steps;
-  if (L < 1) return fail(MTMC_E_ARG, "backward with num_enc_steps == 0 is not implemented");
   const int64_t N = call->n_nodes, E = call->n_edges;
   const int hn = (m->reattach_nodes ? 2 : 1) * MTMC_NODE_DIM;
   hipStream_t s = x.stream;
@@ -72,7 +71,11 @@ static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
   // the workspace side: statistics blocks, per-round dP/dQ, dh0, de0, the first de / dh buffers -- one range
   HIP_OK(hipMemsetAsync(x.ws + lo.bwd_zero, 0, lo.bwd_zero_end - lo.bwd_zero, s));
   int cur = 0, cur_e = 0;
-  if (d_h) HIP_OK(hipMemcpyAsync(g_h[cur], d_h, (size_t)N * 32 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (d_h) HIP_OK(hipMemcpyAsync(L > 0 ? g_h[cur] : g_h0, d_h, (size_t)N * 32 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (L == 0 && d_logits_steps && d_logits_steps[0] && E > 0)       // no rounds: classifier on the encoded edges
+    mtmc::launch_bwd_classify_e0(enc_params(x), call->edge_attr, E, (double)E, m->cls.weight, m->cls.out_dim,
+                                 d_logits_steps[0], g_e0, const_cast<float*>(grads->cls.weight),
+                                 const_cast<float*>(grads->cls.bias), s);
 
   int first_cls = L - m->num_class_steps + 1;
   if (first_cls < 1) first_cls = 1;
@@ -200,7 +203,7 @@ extern "C" int32_t mtmc_mpn_backward(const mtmc_mpn_model* model, const mtmc_mpn
   const float* steps[64];
   int n_out = 0;
   if (model && call && d_logits) {
-    n_out = std::min(model->num_class_steps, model->num_enc_steps);
+    n_out = model->num_enc_steps > 0 ? std::min(model->num_class_steps, model->num_enc_steps) : 1;
     if (n_out > 64) return fail(MTMC_E_ARG, "more than 64 classified steps");
     for (int i = 0; i < n_out; ++i) steps[i] = d_logits + (size_t)i * call->n_edges * model->cls.out_dim;
   }

@@ -53,6 +53,9 @@ void launch_bwd_node_upd(const BwdRoundParams& p, int mode, hipStream_t s);
 void launch_bwd_edge_upd(const BwdRoundParams& p, int mode, hipStream_t s);
 void launch_bwd_node_proj(const BwdProjParams& p, hipStream_t s);
 void launch_bwd_edge_enc(const BwdEncParams& p, int pass, hipStream_t s);
+void launch_bwd_classify_e0(const EdgeEncParams& enc, const float* attr, int64_t n_edges, double e_total, const float* cls_w,
+                            int n_classes, const float* d_logits, float* g_e0, float* gr_cls_w, float* gr_cls_b,
+                            hipStream_t s);
 void launch_bn_bwd(const BnBwdParams& p, int mode, hipStream_t s);
 void launch_transpose_pad(const float* src, int64_t rows, int cols, int64_t ld_src, float* dst, int64_t rows_pad,
                           hipStream_t s);

@@ -614,6 +614,61 @@ void launch_bwd_edge_upd(const BwdRoundParams& p, int mode, hipStream_t s) {
 void launch_bwd_node_proj(const BwdProjParams& p, hipStream_t s) {
   hipLaunchKernelGGL(bwd_node_proj_kernel, dim3(cap((p.n_nodes + 31) / 32)), dim3(256), 0, s, p);
 }
+// L == 0 (reference models/mpn.py:295-297): the classifier sits directly on the encoded edges.
+// d e0 = Wc^T d logits; dWc = sum_e d logits (x) e0; dbc = sum_e d logits.
+__global__ __launch_bounds__(256) void bwd_classify_e0_kernel(EdgeEncParams enc, const float* attr, int64_t n_edges,
+                                                              double e_total, const float* cls_w, int n_classes,
+                                                              const float* d_logits, float* g_e0, float* gr_cls_w,
+                                                              float* gr_cls_b) {
+  __shared__ EdgeEncAffine af;
+  __shared__ double scratch[kStatAttr + kStatEnc2];
+  __shared__ double red[64 * 4];
+  edge_enc_affine_to_smem(enc, e_total, 2, &af, scratch);
+  constexpr int NV = 4 * MTMC_MAX_CLASSES + MTMC_MAX_CLASSES;
+  double acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = 0;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += nthreads) {
+    float a0, a1, u[4], e0[4], de[4] = {0, 0, 0, 0};
+    load_attr(attr, enc.fe, e, a0, a1);
+    edge_enc_hidden(enc, af, e, a0, a1, u);
+    edge_enc_out(enc, af, e, u, e0);
+#pragma unroll
+    for (int c = 0; c < MTMC_MAX_CLASSES; ++c) {
+      if (c < n_classes) {
+        const float dl = d_logits[e * n_classes + c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          de[j] = fmaf(cls_w[c * 4 + j], dl, de[j]);
+          acc[c * 4 + j] += (double)dl * e0[j];
+        }
+        acc[4 * MTMC_MAX_CLASSES + c] += dl;
+      }
+    }
+    reinterpret_cast<float4*>(g_e0)[e] = make_float4(de[0], de[1], de[2], de[3]);
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const double s = wave_sum(acc[i]);
+    if (lane == kWaveSumLane) red[wid * 64 + i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    const int i = threadIdx.x;
+    const double s = red[i] + red[64 + i] + red[128 + i] + red[192 + i];
+    if (i < 4 * MTMC_MAX_CLASSES) { if (i / 4 < n_classes) unsafeAtomicAdd(gr_cls_w + i, (float)s); }
+    else if (i - 4 * MTMC_MAX_CLASSES < n_classes) unsafeAtomicAdd(gr_cls_b + (i - 4 * MTMC_MAX_CLASSES), (float)s);
+  }
+}
+
+void launch_bwd_classify_e0(const EdgeEncParams& enc, const float* attr, int64_t n_edges, double e_total, const float* cls_w,
+                            int n_classes, const float* d_logits, float* g_e0, float* gr_cls_w, float* gr_cls_b,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(bwd_classify_e0_kernel, dim3(cap((n_edges + 255) / 256)), dim3(256), 0, s, enc, attr, n_edges, e_total,
+                     cls_w, n_classes, d_logits, g_e0, gr_cls_w, gr_cls_b);
+}
 void launch_bwd_edge_enc(const BwdEncParams& p, int pass, hipStream_t s) {
   const int grid = cap((p.n_edges + 255) / 256);
   if (pass == 0) hipLaunchKernelGGL(bwd_edge_enc_kernel<0>, dim3(grid), dim3(256), 0, s, p);
