@@ -111,6 +111,7 @@ __global__ __launch_bounds__(1024) void pp_scan_kernel(PpParams p, int n_blocks)
   if (threadIdx.x == 0) {
     p.hdr[0] = total;
     p.hdr[2] = 0;
+    p.hdr[3] = 0;
     p.hdr[1] = total > p.cap ? 1 : 0;                   // more active edges than the workspace was sized for
     p.info[0] = total;
   }
@@ -135,8 +136,14 @@ __global__ __launch_bounds__(256) void pp_compact_kernel(PpParams p) {
     if (on) {
       const int k = out + before + __popcll(b & ((1ull << lane) - 1));
       p.a_idx[k] = (int)e;
-      p.a_u[k] = (int)p.row[e * p.idx_stride];
-      p.a_v[k] = (int)p.col[e * p.idx_stride];
+      int64_t u = p.row[e * p.idx_stride], v = p.col[e * p.idx_stride];
+      if (u < 0 || u >= p.n_nodes || v < 0 || v >= p.n_nodes) {   // never index with it: clamp and report (status 4)
+        p.hdr[3] = 1;
+        u = u < 0 ? 0 : (u >= p.n_nodes ? p.n_nodes - 1 : u);
+        v = v < 0 ? 0 : (v >= p.n_nodes ? p.n_nodes - 1 : v);
+      }
+      p.a_u[k] = (int)u;
+      p.a_v[k] = (int)v;
       p.a_p[k] = p.prob1[e];
       p.alive[k] = 1;
     }
@@ -652,7 +659,7 @@ __global__ __launch_bounds__(kPpThreads) void pp_graph_kernel(PpParams p, int ld
   atomicAdd(&s_alive, alive_cnt);
   __syncthreads();
   if (threadIdx.x == 0) {
-    p.info[1] = s_alive; p.info[2] = n_sets; p.info[3] = status; p.info[4] = split_iters; p.info[5] = walks;
+    p.info[1] = s_alive; p.info[2] = n_sets; p.info[3] = status ? status : (p.hdr[3] ? 4 : 0); p.info[4] = split_iters; p.info[5] = walks;
     p.info[6] = prune_rounds; p.info[7] = p.hdr[2];
   }
 }

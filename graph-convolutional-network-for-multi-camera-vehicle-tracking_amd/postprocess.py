@@ -15,7 +15,8 @@ from . import _lib
 CUTTING, PRUNING, SPLITTING = 1, 2, 4
 _STATUS = {1: "more active edges than max_active: predictions left at argmax",
            2: "over-sized cluster without an active edge",
-           3: "splitting did not finish within 262144 iterations (predictions hold the state reached)"}
+           3: "splitting did not finish within 262144 iterations (predictions hold the state reached)",
+           4: "edge_index holds node ids outside [0, num_nodes) on an active edge (clamped on the device)"}
 
 
 def _flag(v) -> bool:

@@ -242,7 +242,7 @@ int32_t mtmc_cross_entropy_backward(const float* logits, const int64_t* labels, 
  * logits == NULL: prob1 and predictions are INPUTS (reproduces a run from given probabilities exactly).
  * info [8] (int32, device): active edges in, active edges out, clusters, status (0 ok, 1 = more than max_active
  * active edges: predictions left at argmax, 2 = over-sized cluster without an active edge, 3 = splitting iteration cap
- * reached), splitting iterations,
+ * reached, 4 = an active edge named a node outside [0, n_nodes): clamped), splitting iterations,
  * component walks, pruning rounds, 100 MHz ticks spent in the walks.  max_active <= 0: size the workspace for E active edges.
  * row/col: int64 with element stride idx_stride, as in struct mtmc_mpn_call.  Nothing is synchronised or allocated. */
 enum { MTMC_PP_CUTTING = 1, MTMC_PP_PRUNING = 2, MTMC_PP_SPLITTING = 4 };

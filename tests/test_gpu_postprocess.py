@@ -81,3 +81,13 @@ def test_capacity_overflow_is_reported():
     s = pp_cases.scenario(n_ids=20, n_cams=4, seed=5, fp_rate=0.2)
     with pytest.raises(RuntimeError, match="max_active"):
         mtmc_mpn.postprocess(s.logits.to(DEV), s.edge_index.to(DEV), s.n_nodes, s.n_cams, max_active=8)
+
+
+def test_out_of_range_node_ids_are_clamped_and_reported():
+    ei = torch.tensor([[0, 1, 1, 7], [1, 0, 2, 1]], device=DEV)              # node 7 does not exist (N = 3)
+    logits = torch.tensor([[-1.0, 2.0]] * 4, device=DEV)
+    with pytest.raises(RuntimeError, match="outside"):
+        mtmc_mpn.postprocess(logits, ei, 3, 2)
+    out = mtmc_mpn.postprocess(logits, ei, 3, 2, check=False)                # no fault, no exception without the check
+    torch.cuda.synchronize()
+    assert out.info_dev.cpu()[3].item() == 4
