@@ -14,6 +14,6 @@ with torch.no_grad():
     o32, h32 = mpn_oracle.forward(sd, copy.deepcopy(params), "resnet101", d.x, d.edge_index, d.edge_attr)
     out, h = m.cuda()(T.to_gpu(d))
 g = out["classified_edges"][0].cpu().double()
-print(os.environ.get("MTMC_GEMM_BF16X6", "fp32"), "|gpu-fp64| %.2e  |ref32-fp64| %.2e  h rel %.2e  h0-path rel(h32) %.2e" % (
+print("f16x3" if not (os.environ.get("MTMC_GEMM_NO_F16") or os.environ.get("MTMC_GEMM_FP32")) else ("bf16x6" if not os.environ.get("MTMC_GEMM_FP32") else "fp32"), "|gpu-fp64| %.2e  |ref32-fp64| %.2e  h rel %.2e  h0-path rel(h32) %.2e" % (
     (g - o64["classified_edges"][0]).abs().max(), (o32["classified_edges"][0].double() - o64["classified_edges"][0]).abs().max(),
     ((h.cpu().double() - h64).abs().max() / h64.abs().max()), ((h32.double() - h64).abs().max() / h64.abs().max())))
