@@ -1,0 +1,49 @@
+"""Seeded random sweep over the configuration family (L, Cs, aggregation, reattach flags, edge feature width, graph
+shape and edge order) against the fp64 oracle: catches interactions the named fixtures do not pair up."""
+import copy
+import types
+
+import pytest
+import torch
+
+import mtmc_mpn
+from mtmc_mpn import graphs
+from oracle import mpn_oracle
+
+pytestmark = pytest.mark.gpu
+ARCH = "resnet101"
+
+
+def _case(seed):
+    g = torch.Generator().manual_seed(1000 + seed)
+    r = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    over = dict(num_enc_steps=r(0, 3), num_class_steps=r(1, 3), node_agg_fn=["sum", "mean", "max"][r(0, 2)],
+                reattach_initial_nodes=bool(r(0, 1)), reattach_initial_edges=bool(r(0, 1)))
+    kind = r(0, 2)
+    if kind == 0:
+        d = graphs.random_graph(r(8, 300), r(16, 4000), 2048, seed=seed)
+    else:
+        cams = [r(3, 60) for _ in range(r(2, 5))]
+        d = graphs.camera_graph(tuple(cams), 2048, seed=seed)
+        if kind == 2:                                        # same graph, edges in random order
+            perm = torch.randperm(d.edge_index.shape[1], generator=g)
+            d.edge_index, d.edge_attr = d.edge_index[:, perm].contiguous(), d.edge_attr[perm].contiguous()
+    return over, d
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_configuration(seed):
+    over, d = _case(seed)
+    params = mtmc_mpn.default_params(**over)
+    torch.manual_seed(seed)
+    m = mtmc_mpn.MOTMPNet(copy.deepcopy(params), None, ARCH).eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        want, want_h = mpn_oracle.forward(sd, copy.deepcopy(params), ARCH, d.x, d.edge_index, d.edge_attr, dtype=torch.float64)
+        m = m.cuda()
+        out, h = m(types.SimpleNamespace(x=d.x.cuda(), edge_index=d.edge_index.cuda(), edge_attr=d.edge_attr.cuda()))
+    assert len(out["classified_edges"]) == len(want["classified_edges"]), over
+    for a, b in zip(out["classified_edges"], want["classified_edges"]):
+        assert (a.cpu().double() - b).abs().max().item() <= 1e-4, (over, d.x.shape, d.edge_index.shape)
+    scale = max(1.0, want_h.abs().max().item())
+    assert (h.cpu().double() - want_h).abs().max().item() <= 1e-4 * scale, over
