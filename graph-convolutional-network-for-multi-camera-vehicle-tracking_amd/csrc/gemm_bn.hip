@@ -465,9 +465,12 @@ __global__ __launch_bounds__(256) void gemm_bn_f16x3_kernel(GemmParams p, int ti
     const float aw = __uint_as_float(uw);
     if (bound > 0.f && bound < 3e38f) (void)frexpf(bound, &ea);
     if (aw > 0.f && aw < 3e38f) (void)frexpf(aw, &ew);
+    ea = ea < -100 ? -100 : (ea > 100 ? 100 : ea);        // keep every factor (and their product's two halves) finite
+    ew = ew < -100 ? -100 : (ew > 100 ? 100 : ew);
     sc[0] = ldexpf(1.f, 14 - ea);
     sc[1] = ldexpf(1.f, 14 - ew);
-    sc[2] = ldexpf(1.f, ea + ew - 28);
+    sc[2] = ldexpf(1.f, ea - 14);                         // undone in two steps: the product could leave fp32's range
+    sc[3] = ldexpf(1.f, ew - 14);
   }
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -586,7 +589,7 @@ __global__ __launch_bounds__(256) void gemm_bn_f16x3_kernel(GemmParams p, int ti
     }
   }
 
-  const float inv = sc[2];
+  const float inv_a = sc[2], inv_w = sc[3];
   if (p.split_k > 1) {
     float* slab = p.slab + (size_t)blockIdx.y * p.M * p.Nout;
 #pragma unroll
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(256) void gemm_bn_f16x3_kernel(GemmParams p, int ti
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int64_t row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (row < p.M && col < p.Nout) slab[row * p.Nout + col] = acc[i][j][r] * inv;
+          if (row < p.M && col < p.Nout) slab[row * p.Nout + col] = acc[i][j][r] * inv_a * inv_w;
         }
     }
     return;
@@ -617,7 +620,7 @@ __global__ __launch_bounds__(256) void gemm_bn_f16x3_kernel(GemmParams p, int ti
       for (int r = 0; r < 16; ++r) {
         const int64_t row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < p.M && col < p.Nout) {
-          const float y = fmaf(acc[i][j][r], inv, bias);
+          const float y = fmaf(acc[i][j][r] * inv_a, inv_w, bias);
           p.Y[row * p.ldy + col] = y;
           ymax = fmaxf(ymax, fabsf(y));
           cs += y;

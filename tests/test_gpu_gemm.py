@@ -43,7 +43,7 @@ def test_against_fp64(shape):
         assert torch.allclose(st[N:], (ref * ref).sum(0), rtol=1e-5, atol=0)
 
 
-@pytest.mark.parametrize("scale_a, scale_w", [(1e-4, 1.0), (300.0, 1e-3), (1.0, 40.0)])
+@pytest.mark.parametrize("scale_a, scale_w", [(1e-4, 1.0), (300.0, 1e-3), (1.0, 40.0), (1e-25, 1e-8), (1e12, 1e10)])
 def test_operand_ranges(scale_a, scale_w):
     """The power-of-two operand scaling keeps tiny and large inputs inside fp16's range."""
     g = torch.Generator().manual_seed(5)
