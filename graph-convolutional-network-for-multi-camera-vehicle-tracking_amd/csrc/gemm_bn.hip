@@ -505,6 +505,17 @@ __global__ __launch_bounds__(256) void gemm_bn_f16x3_kernel(GemmParams p, int ti
     // residual x - h1 is exact, 22 mantissa bits are kept.  Deliberately NOT `(_Float16)x`: hipcc 7.2 lowers that
     // to v_cvt_pk_f16_f32 / v_fma_mix{lo,hi}_f16 sequences which, with two or more of these workgroups resident on
     // a CU, sporadically left zeros in the pieces written by lanes 48-63 (reproducer: tools/dbg_gemm.py)
+#ifdef MTMC_F16_CVT_RNE   // reproduces the hazard: make clean && make EXTRA=-DMTMC_F16_CVT_RNE && python tools/dbg_gemm.py 9000 2048 1024
+    {
+      const float xs[4] = {x0, x1, x2, x3};
+      f16x4 q1r, q2r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const _Float16 h1 = (_Float16)xs[j]; q1r[j] = h1; q2r[j] = (_Float16)(xs[j] - (float)h1); }
+      *reinterpret_cast<f16x4*>(base + r * LDB + c4 * 4) = q1r;
+      *reinterpret_cast<f16x4*>(base + piece_stride + r * LDB + c4 * 4) = q2r;
+      return;
+    }
+#endif
     const h2_t a01 = __builtin_amdgcn_cvt_pkrtz(x0, x1), a23 = __builtin_amdgcn_cvt_pkrtz(x2, x3);
     const h2_t b01 = __builtin_amdgcn_cvt_pkrtz(x0 - (float)a01[0], x1 - (float)a01[1]);
     const h2_t b23 = __builtin_amdgcn_cvt_pkrtz(x2 - (float)a23[0], x3 - (float)a23[1]);
