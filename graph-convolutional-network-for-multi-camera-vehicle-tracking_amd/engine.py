@@ -31,10 +31,14 @@ class ForwardEngine:
         self.spec: MpnSpec = module.spec
         self.lib = _lib.load()
         self._ws = {}
+        self._layers = None             # param_layers(): the module tree is fixed after construction
+        self._ms_key, self._ms = None, None
 
     # -- parameters -> mtmc_mpn_model ------------------------------------------------------------
     def param_layers(self):
         """(struct slot, Linear, BatchNorm or None, LayerSpec) for every layer, in mtmc_mpn_model order."""
+        if self._layers is not None:
+            return self._layers
         m, s = self.module, self.spec
         out = []
         for i, layer in enumerate(s.enc_node):
@@ -44,9 +48,15 @@ class ForwardEngine:
         out.append((("upd_edge", None),) + _lin(m.MPNet.edge_model.edge_mlp, s.upd_edge[0]) + (s.upd_edge[0],))
         out.append((("upd_node", None),) + _lin(m.MPNet.node_model.node_mlp, s.upd_node[0]) + (s.upd_node[0],))
         out.append((("cls", None),) + _lin(m.classifier.edge_mlp, s.cls_edge[0]) + (s.cls_edge[0],))
+        self._layers = out
         return out
 
     def model_struct(self, dev) -> _lib.Model:
+        # the struct only changes when a parameter's storage does: key it on the 34 device pointers
+        key = (dev,) + tuple(t.data_ptr() for _, lin, bn, _ in self.param_layers()
+                             for t in ((lin.weight, lin.bias) if bn is None else (lin.weight, lin.bias, bn.weight, bn.bias)))
+        if key == self._ms_key:
+            return _lib.Model.from_buffer_copy(self._ms)
         m, s = self.module, self.spec
         out = _lib.Model()
 
@@ -73,7 +83,8 @@ class ForwardEngine:
         out.agg = _lib.AGG[s.agg]
         out.num_enc_steps, out.num_class_steps = s.num_enc_steps, s.num_class_steps
         out.reattach_nodes, out.reattach_edges = int(s.reattach_nodes), int(s.reattach_edges)
-        return out
+        self._ms_key, self._ms = key, out
+        return _lib.Model.from_buffer_copy(out)
 
     def workspace(self, model, n, e, dev, stream_ptr) -> torch.Tensor:
         need = self.lib.mtmc_mpn_workspace_bytes(C.byref(model), n, e)
