@@ -436,6 +436,8 @@ def main():
         line["stress"] = st
         # the multi-GPU workload (config 5) on this one GPU: the N=1 point of the strong-scaling curve
         line["scale_base"] = run_single("cfg5", device, 5, 2, with_cpu=False, phase_iters=2)
+        line["scale_base"]["note"] = ("1-GPU point of the strong-scaling series that `--gpus N` (N > 1) reports: the same "
+                                      "1M-node / 100M-edge graph, one call, no collectives")
         line["graph_build"] = run_graph_build(device, with_cpu=not args.no_cpu)
         line["training_step"] = run_training_step(device)
         line["postprocess"] = run_postprocess(device, with_cpu=not args.no_cpu)

@@ -143,6 +143,10 @@ def main_distributed(args):
                              "frac": b_fwd / sec / 1e9 / (bench.HBM_PEAK_GBS * world), "traffic": None,
                              "kernel": "whole forward (SURVEY 8(d) algorithmic bytes over the step time, all ranks)"},
                 "cpu_baseline": None, "headline_graph_on_these_ranks": s02,
+                "scaling_note": ("north_star asks for the S02 graph at 1 GPU and the 1M-node / 100M-edge graph at 1/2/4/8 GPUs: "
+                                 "this line is the latter; its 1-GPU point is `scale_base.value` of the `--gpus 1` line "
+                                 "(whose headline `value` is the S02 graph), so compare against that, not against the "
+                                 "headline"),
                 "forward_algorithmic": {"bytes": b_fwd, "GBps": b_fwd / sec / 1e9,
                                         "frac_of_aggregate_hbm_peak": b_fwd / sec / 1e9 / (bench.HBM_PEAK_GBS * world)},
                 "rank0_split": split}
