@@ -41,3 +41,17 @@ def test_workspace_sizing_needs_no_gpu():
     lay = _lib.WsLayout()
     assert lib.mtmc_mpn_workspace_layout(ctypes.byref(model), 450, 150454, ctypes.byref(lay)) == 0
     assert lay.total_bytes == small and lay.zero_bytes < lay.h0_off
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/mtmc_mpn.h is a C ABI: it must compile as C99 (and C++11) on its own."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        import pytest
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text('#include "mtmc_mpn.h"\nint main(void) { return sizeof(mtmc_mpn_call) > 0 ? 0 : 1; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)], check=True)
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", "-x", "c++", str(src)], check=True)
