@@ -704,7 +704,7 @@ static void launch_bf16x6(const GemmParams& p, hipStream_t s) {
 // and the fp64 column statistics of Y.  Block = 64 columns x kCombRows rows; thread = one column, every 4th row;
 // all of a row's slice loads are issued together (they are independent; only the additions are ordered).
 constexpr int kCombRows = 16;
-constexpr int kMaxSplit = 8;
+constexpr int kMaxSplit = 4;   // 8 measured slower with the fp16 kernel (S02 165.7 vs 161.4 us: half the slab traffic)
 
 __global__ __launch_bounds__(256) void combine_stats_kernel(GemmParams p) {
   __shared__ double red[2 * 4 * 64];
