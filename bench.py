@@ -94,7 +94,7 @@ def pmc_traffic(workload, kernel):
 
 def encoder_kernel(n_rows, layer):
     """Which GEMM kernel csrc/gemm_bn.hip:gemm_plan picks for an encoder layer (mirrors its rule)."""
-    big = ((n_rows + 127) // 128) * ((layer.out_dim + 127) // 128) >= 512 and layer.out_dim >= 128
+    big = ((n_rows + 127) // 128) * ((layer.out_dim + 127) // 128) >= 256 and layer.out_dim >= 128
     if os.environ.get("MTMC_GEMM_FP32"):
         return "gemm_bn_kernel"
     if os.environ.get("MTMC_GEMM_NO_F16"):

@@ -801,7 +801,7 @@ int gemm_plan(int64_t M, int K, int Nout, int* split_k) {
   *split_k = 1;
   if (K % 32 != 0 || K > 6144) return 0;
   const int64_t big_tiles = ((M + 127) / 128) * ((Nout + 127) / 128);
-  if (big_tiles >= 512 && Nout >= 128) return 2;
+  if (big_tiles >= 256 && Nout >= 128) return 2;   // one 128x128 tile per CU or more (fp16 kernel: 256 beats 512 at M = 6000)
   const int64_t tiles = ((M + 63) / 64) * ((Nout + 63) / 64);
   int s = 1;
   while (s < kMaxSplit && tiles * (s * 2) <= 1024 && K % (s * 2 * BK) == 0 && K / (s * 2) >= 64) s *= 2;
