@@ -142,8 +142,9 @@ __device__ __forceinline__ void edge_z1(const RoundParams& p, const EdgeEncAffin
                                         int64_t e, int& r, float (&z)[4]) {
   r = p.row32[e];
   const int c = p.col32[e];
-  const float4 pr = *reinterpret_cast<const float4*>(p.P + (int64_t)r * 8);
-  const float4 pc = *reinterpret_cast<const float4*>(p.P + (int64_t)c * 8 + 4);
+  // P = [Pr: N x 4 | Pc: N x 4]: the randomly gathered half is a compact 16 B/node table (four nodes per 64-byte sector)
+  const float4 pr = *reinterpret_cast<const float4*>(p.P + (int64_t)r * 4);
+  const float4 pc = *reinterpret_cast<const float4*>(p.P + ((int64_t)p.n_nodes + c) * 4);
   float e0[4] = {0, 0, 0, 0}, ep[4];
   if (p.first_round || p.reattach_edges) {
     float a0, a1, u[4];

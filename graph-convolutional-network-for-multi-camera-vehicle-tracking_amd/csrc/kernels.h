@@ -27,7 +27,7 @@ struct RoundParams {
   float* e_buf;              // [E][4] this round: z1 written by pass A
   float* e_out;              // [E][4] e' written by pass B, read by pass C (eval: == e_buf, in place; training: kept apart)
   Drop drop_e, drop_n; unsigned drop_stream;   // training: dropout of the edge / node update MLPs
-  const float* P;            // [N][8]  Pr | Pc
+  const float* P;            // [2][N][4]: Pr rows, then Pc rows (the gathered half compact)
   const float* Q;            // [N][32]
   const float* ue_w; const float* ue_b; const float* ue_g; const float* ue_bt; int ue_ld; int ue_eoff;
   const float* un_w; const float* un_b; const float* un_g; const float* un_bt; int un_ld; int un_eoff;

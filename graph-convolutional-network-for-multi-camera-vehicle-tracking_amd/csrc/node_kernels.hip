@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void node_proj_kernel(NodeProjParams p) {
     }
     const int64_t node = node0 + nl;
     if (node < p.n_nodes) {
-      p.P[node * 8 + part] = acc[0];
+      p.P[(part < 4 ? node : p.n_nodes + node) * 4 + (part & 3)] = acc[0];      // [Pr | Pc], see edge_z1
 #pragma unroll
       for (int i = 1; i < 5; ++i) p.Q[node * kH + part + 8 * (i - 1)] = acc[i];
     }
