@@ -74,6 +74,36 @@ __global__ __launch_bounds__(256) void ce_backward_kernel(const float* logits, c
   }
 }
 
+// Confusion counts of argmax(logits) against 0/1 labels in one pass: what the training / validation loops derive their
+// FPR, TPR, precision and recall from (reference train.py:98-107, inference.py:20-67) with boolean-mask indexing, i.e.
+// with a device synchronisation per mask.  counts = {TP, FP, TN, FN}; labels other than 0 / 1 are skipped.
+__global__ __launch_bounds__(256) void confusion_kernel(const float* logits, const int64_t* labels, int64_t n, int C,
+                                                        unsigned long long* counts) {
+  __shared__ unsigned int sh[4];
+  if (threadIdx.x < 4) sh[threadIdx.x] = 0;
+  __syncthreads();
+  unsigned int c[4] = {0, 0, 0, 0};
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthreads) {
+    const int64_t y = labels[i];
+    if (y != 0 && y != 1) continue;
+    int best = 0;
+    float bv = logits[i * C];
+    for (int k = 1; k < C; ++k) { const float v = logits[i * C + k]; if (v > bv) { bv = v; best = k; } }   // first maximum
+    const int pred = best == 1;
+    ++c[y == 1 ? (pred ? 0 : 3) : (pred ? 1 : 2)];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned int v = c[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sh[j], v);
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 && sh[threadIdx.x]) atomicAdd(counts + threadIdx.x, (unsigned long long)sh[threadIdx.x]);
+}
+
 static inline int ce_grid(int64_t n) {
   const int64_t b = (n + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -106,6 +136,17 @@ int32_t mtmc_cross_entropy_backward(const float* logits, const int64_t* labels, 
   if (n > 0)
     hipLaunchKernelGGL(mtmc::ce_backward_kernel, dim3(mtmc::ce_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        logits, labels, weight, n, n_classes, ignore_index, mode, grad, sums, d_logits);
+  return hipGetLastError() == hipSuccess ? MTMC_OK : MTMC_E_HIP;
+}
+
+int32_t mtmc_edge_confusion(const float* logits, const int64_t* labels, int64_t n, int32_t n_classes, int64_t* counts,
+                            void* stream) {
+  if (!logits || !labels || !counts || n < 0 || n_classes < 2 || n_classes > MTMC_MAX_CLASSES) return MTMC_E_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(counts, 0, 4 * sizeof(int64_t), s) != hipSuccess) return MTMC_E_HIP;
+  if (n > 0)
+    hipLaunchKernelGGL(mtmc::confusion_kernel, dim3(mtmc::ce_grid(n) > 256 ? 256 : mtmc::ce_grid(n)), dim3(256), 0, s, logits,
+                       labels, n, n_classes, reinterpret_cast<unsigned long long*>(counts));
   return hipGetLastError() == hipSuccess ? MTMC_OK : MTMC_E_HIP;
 }
 

@@ -5,6 +5,8 @@
   mlp_forward                                `MLP.forward` (reference models/mlp.py:32-33), eval mode
   cross_entropy                              `F.cross_entropy(input, target, weight, reduction=...)` on the [E, C<=4]
       edge logits, forward and backward fused (the training callers' loss, reference train.py:88-93, :109-142)
+  edge_confusion                             TP / FP / TN / FN of argmax(logits) against the edge labels in one pass,
+      without the device synchronisations of boolean-mask indexing (reference train.py:98-107, inference.py:20-67)
 
 All of them run HIP kernels through the C ABI; CPU tensors are refused.
 """
@@ -157,3 +159,18 @@ def cross_entropy(input, target, weight=None, reduction: str = "mean", ignore_in
         if weight.numel() != input.shape[1]:
             raise RuntimeError("mtmc_mpn.cross_entropy: weight must have one entry per class")
     return _CrossEntropy.apply(input, target.contiguous().long(), weight, _REDUCTIONS[reduction], int(ignore_index))
+
+
+def edge_confusion(logits, labels):
+    """int64 tensor [TP, FP, TN, FN] (on the device) of `argmax(logits, 1) == 1` against 0/1 `labels`; e.g.
+    FPR = FP / (FP + TN) as in train.py:100-102.  No host synchronisation."""
+    if not (logits.is_cuda and labels.is_cuda):
+        raise RuntimeError("mtmc_mpn.edge_confusion: tensors must be on a ROCm GPU (no CPU path)")
+    if logits.dim() != 2 or logits.dtype != torch.float32 or not 2 <= logits.shape[1] <= 4 or labels.shape != logits.shape[:1]:
+        raise NotImplementedError("mtmc_mpn.edge_confusion: logits must be float32 [E, 2..4], labels [E]")
+    x, y = logits.contiguous(), labels.contiguous().long()
+    out = torch.empty(4, dtype=torch.int64, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mtmc_edge_confusion(x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(),
+                                                   _stream(x.device)))
+    return out

@@ -232,6 +232,12 @@ int32_t mtmc_cross_entropy_backward(const float* logits, const int64_t* labels, 
                                     int32_t n_classes, int64_t ignore_index, int32_t mode, const float* grad,
                                     const double* sums, float* d_logits, void* stream);
 
+/* counts[4] (int64, device) = {TP, FP, TN, FN} of argmax(logits [n][n_classes]) against 0/1 labels [n], in one pass:
+ * the confusion counts the training / validation loops compute with boolean-mask indexing (reference train.py:98-107,
+ * inference.py:20-67).  Labels other than 0 / 1 are skipped; prediction = (argmax == 1), first maximum on ties. */
+int32_t mtmc_edge_confusion(const float* logits, const int64_t* labels, int64_t n, int32_t n_classes, int64_t* counts,
+                            void* stream);
+
 /* ---- post-processing of the last logits (replaces reference inference.py:475-489, post_processing
  * inference.py:70-169 and utils.py compute_SCC_and_Clusters :30-52, splitting :54-123, remove_edges_single_direction
  * :125-142, pruning :144-339) ----

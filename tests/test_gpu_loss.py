@@ -56,3 +56,19 @@ def test_errors():
         ops.cross_entropy(torch.zeros(4, 7, device=DEV), torch.zeros(4, dtype=torch.long, device=DEV))
     with pytest.raises(ValueError):
         ops.cross_entropy(torch.zeros(4, 2, device=DEV), torch.zeros(4, dtype=torch.long, device=DEV), reduction="avg")
+
+
+def test_edge_confusion_counts():
+    g = torch.Generator().manual_seed(9)
+    n = 50021
+    x = torch.randn(n, 2, generator=g)
+    x[::50] = 0.25                                                   # ties: argmax picks class 0
+    y = (torch.rand(n, generator=g) < 0.1).long()
+    pred = torch.argmax(x, 1)
+    want = [int(((pred == 1) & (y == 1)).sum()), int(((pred == 1) & (y == 0)).sum()),
+            int(((pred == 0) & (y == 0)).sum()), int(((pred == 0) & (y == 1)).sum())]
+    got = ops.edge_confusion(x.to(DEV), y.to(DEV)).cpu().tolist()
+    assert got == want
+    # the reference's FPR (train.py:100-102)
+    fp = torch.sum(pred[y == 0]); tn = pred[y == 0].shape[0] - fp
+    assert abs(got[1] / (got[1] + got[2]) - float(fp / (fp + tn))) < 1e-6      # torch divides in float32
