@@ -171,6 +171,21 @@ def time_phases(model, data, iters):
     return seq, [s / iters for s in sums]
 
 
+def empty_event_pair_ms(n=200):
+    """What a start/stop event pair reads with NOTHING between them on this box (about 5 us): the floor under every
+    per-kernel figure of time_phases.  Reported beside the roofline, never subtracted (with a kernel in between part
+    of it overlaps: rocprofv3's kernel duration sits between raw and raw - floor)."""
+    evs = []
+    for _ in range(n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    v = sorted(a.elapsed_time(b) for a, b in evs)
+    return v[n // 2]
+
+
 def cpu_baseline(name, params, sd, data, max_seconds=25.0):
     """The CPU oracle (bit-equal to the reference's CPU PyTorch path in the build container) timed on
     this host's cores, on a bounded sample of the workload."""
@@ -267,7 +282,7 @@ def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
         achieved, peak, unit = work / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
     roofline = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
                 "traffic": None, "kernel": dom_key, "avg_kernel_ms": avg_ms, "launches_per_step": len(launches),
-                "algorithmic_per_launch": work}
+                "algorithmic_per_launch": work, "event_pair_floor_ms": empty_event_pair_ms()}
     if peak_note:
         roofline["peak_note"] = peak_note
     roofline["traffic"] = pmc_traffic(name, dom_key)

@@ -171,4 +171,32 @@ int32_t mtmc_linear_raw(const float* A, int64_t lda, const float* W, const float
   return e == hipSuccess ? MTMC_OK : fail(MTMC_E_HIP, "launch failed: %s", hipGetErrorString(e));
 }
 
+int32_t mtmc_linear_presplit_raw(const float* A, int64_t lda, const float* W, const float* bias, float* Y, int64_t M,
+                                 int32_t K, int32_t N, void* work, uint64_t work_bytes, uint32_t* scratch, double* stats,
+                                 int32_t variant, void* stream) {
+  if (!A || !W || !bias || !Y || !work || !scratch || M < 1 || K < 64 || K % 64 || K > 2048 || N < 1)
+    return fail(MTMC_E_ARG, "bad arguments");
+  const uint64_t a_bytes = (uint64_t)M * K * 4, w_bytes = (uint64_t)N * K * 4;
+  const uint64_t ia_off = a_bytes, wh_off = (ia_off + (uint64_t)M * 4 + 255) / 256 * 256, iw_off = wh_off + w_bytes;
+  if (work_bytes < iw_off + (uint64_t)N * 4) return fail(MTMC_E_ARG, "work buffer too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(scratch, 0, 3 * mtmc::kAmaxRep * sizeof(uint32_t), s) != hipSuccess) return fail(MTMC_E_HIP, "hipMemsetAsync failed");
+  if (stats && hipMemsetAsync(stats, 0, 2 * (size_t)N * sizeof(double), s) != hipSuccess) return fail(MTMC_E_HIP, "hipMemsetAsync failed");
+  unsigned char* wk = static_cast<unsigned char*>(work);
+  if (variant >= 0) {
+    mtmc::launch_split_rows(A, lda, M, K, wk, reinterpret_cast<float*>(wk + ia_off), s);
+    mtmc::launch_split_rows(W, K, N, K, wk + wh_off, reinterpret_cast<float*>(wk + iw_off), s);
+  } else {
+    variant = -variant - 1;          // negative: the planes in `work` are reused (times the GEMM alone)
+  }
+  mtmc::SplitGemmParams g;
+  g.Ah = reinterpret_cast<const _Float16*>(wk); g.inv_a = reinterpret_cast<const float*>(wk + ia_off);
+  g.Wh = reinterpret_cast<const _Float16*>(wk + wh_off); g.inv_w = reinterpret_cast<const float*>(wk + iw_off);
+  g.bias = bias; g.Y = Y; g.ldy = N; g.stats_out = stats; g.amax_y = scratch + 2 * mtmc::kAmaxRep;
+  g.M = M; g.K = K; g.Nout = N;
+  if (mtmc::launch_gemm_presplit(g, s, variant) != 0) return fail(MTMC_E_ARG, "unsupported shape");
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MTMC_OK : fail(MTMC_E_HIP, "launch failed: %s", hipGetErrorString(e));
+}
+
 }  // extern "C"

@@ -85,6 +85,20 @@ struct GemmParams {
   unsigned* amax_y = nullptr;        // out (atomicMax): of this layer's raw Y
 };
 
+// First encoder layer on pre-split operands (gemm_presplit.hip): fp16 planes [2][rows][K] and one power-of-two
+// inverse scale per row, written by launch_split_rows.
+struct SplitGemmParams {
+  const _Float16* Ah; const float* inv_a;   // [2][M][K], [M]
+  const _Float16* Wh; const float* inv_w;   // [2][Nout][K], [Nout]
+  const float* bias;
+  float* Y; int64_t ldy;
+  double* stats_out;                        // f64[2*Nout], accumulated atomically (or nullptr)
+  unsigned* amax_y;                         // u32[kAmaxRep] (atomicMax) or nullptr
+  int64_t M; int K; int Nout;
+};
+void launch_split_rows(const float* X, int64_t ld, int64_t rows, int K, void* H, float* inv, hipStream_t s);
+int launch_gemm_presplit(const SplitGemmParams& p, hipStream_t s, int variant = 0);   // 0 ok, 1 unsupported shape
+
 void launch_prep(const PrepParams& p, hipStream_t s);
 void launch_enc2(const EdgeEncParams& enc, const float* attr, int64_t n_edges, double e_total, double* stat_enc2,
                  hipStream_t s);

@@ -1,0 +1,75 @@
+"""Experimental pre-split GEMM (csrc/gemm_presplit.hip, mtmc_linear_presplit_raw) against float64: every tile /
+pipeline variant, ragged edges, rows of very different magnitude, zero rows.  Same bound as the in-loop split kernel:
+|err| <= 3e-7 * (sum_k |a||w| + |b|)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(lib, A, W, b, variant, work=None):
+    from mtmc_mpn import _lib
+    M, K = A.shape
+    N = W.shape[0]
+    Y = torch.full((M, N), float("nan"), device="cuda")
+    if work is None:
+        work = torch.empty(4 * M * K + 4 * N * K + 4 * (M + N) + 1024, dtype=torch.uint8, device="cuda")
+    scr = torch.zeros(48, dtype=torch.int32, device="cuda")
+    st = torch.empty(2 * N, dtype=torch.float64, device="cuda")
+    _lib.check(lib.mtmc_linear_presplit_raw(A.data_ptr(), A.stride(0), W.data_ptr(), b.data_ptr(), Y.data_ptr(), M, K, N,
+                                            work.data_ptr(), work.numel(), scr.data_ptr(), st.data_ptr(), variant,
+                                            torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    return Y, st, scr[32:48].view(torch.float32).max().item(), work
+
+
+@pytest.mark.parametrize("shape", [(129, 64, 128), (300, 512, 130), (777, 2048, 1024), (1030, 1024, 520)])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+def test_presplit_matches_float64(shape, variant):
+    from mtmc_mpn import _lib
+    lib = _lib.load()
+    M, K, N = shape
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N)
+    A = torch.randn(M, K, device="cuda", generator=g) * torch.exp(3 * torch.randn(M, 1, device="cuda", generator=g))
+    A[M // 2] = 0                                            # an all-zero row: scale 1, exact zeros
+    W = (torch.rand(N, K, device="cuda", generator=g) * 2 - 1) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    Y, st, ymax, _ = _run(lib, A, W, b, variant)
+    ref = A.double() @ W.double().t() + b.double()
+    bound = A.double().abs() @ W.double().abs().t() + b.double().abs()
+    assert torch.isfinite(Y).all()
+    assert ((Y.double() - ref).abs() / bound).max().item() < 3e-7
+    assert torch.equal(Y[M // 2], b)                         # zero row: bias only, exactly
+    assert ymax == Y.abs().max().item()
+    assert torch.allclose(st[:N], Y.double().sum(0), rtol=1e-9, atol=1e-9 * Y.abs().max().item() * M)
+    assert torch.allclose(st[N:], (Y.double() ** 2).sum(0), rtol=1e-9)
+
+
+def test_presplit_strided_rows_and_reused_planes():
+    from mtmc_mpn import _lib
+    lib = _lib.load()
+    M, K, N = 400, 256, 200
+    g = torch.Generator(device="cuda").manual_seed(5)
+    big = torch.randn(M, K + 64, device="cuda", generator=g)
+    A = big[:, :K]                                           # row stride K + 64
+    W = torch.randn(N, K, device="cuda", generator=g)
+    b = torch.zeros(N, device="cuda")
+    Y0, _, _, work = _run(lib, A, W, b, 0)
+    Y1, _, _, _ = _run(lib, A, W, b, -1, work)               # variant -1: planes already in `work`, variant 0
+    assert torch.equal(Y0, Y1)
+    ref = A.double() @ W.double().t()
+    assert ((Y0.double() - ref).abs() / (A.double().abs() @ W.double().abs().t())).max().item() < 3e-7
+
+
+def test_presplit_rejects_bad_shapes():
+    from mtmc_mpn import _lib
+    lib = _lib.load()
+    A = torch.randn(8, 96, device="cuda")
+    W = torch.randn(8, 96, device="cuda")
+    b = torch.zeros(8, device="cuda")
+    with pytest.raises(RuntimeError):
+        _run(lib, A, W, b, 0)                                # K % 64 != 0
+    A = torch.randn(8, 64, device="cuda")
+    W = torch.randn(8, 64, device="cuda")
+    with pytest.raises(RuntimeError):
+        _run(lib, A, W, b, 0, work=torch.empty(64, dtype=torch.uint8, device="cuda"))   # work too small
