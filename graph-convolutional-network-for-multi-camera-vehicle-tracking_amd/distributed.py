@@ -86,12 +86,13 @@ class ShardedForward:
             recv = h.new_empty((world * longest, h.shape[1]))
             dist.all_gather_into_tensor(recv, send, group=self.group)
             parts = recv.view(world, longest, h.shape[1])
-        else:
-            parts = [torch.empty_like(send) for _ in range(world)]
-            dist.all_gather(parts, send, group=self.group)
+        else:                                      # gloo (tests): no all-gather of device tensors, stage on the host
+            host = send.cpu()
+            parts = [torch.empty_like(host) for _ in range(world)]
+            dist.all_gather(parts, host, group=self.group)
         for r, (rlo, rhi) in enumerate(row_ranges):
             if r != rank and rhi > rlo:
-                h[rlo:rhi] = parts[r][:rhi - rlo]
+                h[rlo:rhi] = parts[r][:rhi - rlo].to(h.device)
 
     def __call__(self, x_local, node_range, edge_index_local, edge_attr_local, n_edges_total, row_ranges=None):
         """x_local: rows [node_range[0], node_range[1]) of x; node_range = (lo, hi, N).
@@ -160,8 +161,8 @@ def row_ranges_of(edge_index_local, group=None):
         dist.all_gather_into_tensor(allr, mine, group=group)
         allr = allr.view(world, 2).tolist()
     else:
-        parts = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine, group=group)
+        parts = [torch.empty(2, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(parts, mine.cpu(), group=group)
         allr = [p.tolist() for p in parts]
     ranges = [(int(a), int(b)) for a, b in allr]
     live = sorted(r for r in ranges if r[1] > r[0])
