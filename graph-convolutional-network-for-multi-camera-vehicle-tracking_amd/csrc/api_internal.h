@@ -36,9 +36,10 @@ struct Layout {
   // training: every round keeps its own buffers (the workspace is the backward tape) + backward scratch
   bool training;
   std::vector<size_t> z_tr, e_tr, h_tr;       // per round: z1 [E][4], e' [E][4], aggregated h [N][32]
-  size_t g_e[2], g_e0, g_h[2], g_h0, g_P, g_Q, g_dz2, g_arg;   // gradients wrt e_r, e0, h_r, h0, P, Q; dz2 [E][32]
+  size_t g_e[2], g_e0, g_h[2], g_h0, g_P, g_Q, g_de2, g_arg;   // gradients wrt e_r, e0, h_r, h0, P, Q; A^T dz2 [E][4]
   size_t bst;                                  // f64[2L+1][kStatRep][kBwdStride] backward statistics blocks
   size_t bwd_zero, bwd_zero_end;               // the range the backward clears with one memset
+  size_t gacc;                                 // f32[kGradRep][kGaccN] (train_kernels.h)
   size_t gA, gB, tA, tB, tW, zeros, bst_n;     // node-encoder backward: gradient ping-pong, transposes, 0-bias, column stats
 };
 constexpr int kBwdStride = 256;                // doubles per replica of the backward statistics scratch
@@ -129,6 +130,7 @@ inline void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* l
     lo->bwd_zero = off;
     lo->bst = take((size_t)(2 * L + 1) * mtmc::kStatRep * kBwdStride * sizeof(double));   // per round: node, edge; + encoder
     lo->bst_n = take(bn_stats * sizeof(double));
+    lo->gacc = take((size_t)16 * 256 * sizeof(float));                   // [kGradRep][kGaccN] small-gradient replicas
     lo->g_P = take((size_t)(L > 0 ? L : 1) * 16 * N * 8 * sizeof(float)); // per round: [kGradRep = 16][N][8]
     lo->g_Q = take((size_t)(L > 0 ? L : 1) * N * 32 * sizeof(float));     // per round
     lo->zeros = take(maxd * sizeof(float));
@@ -139,7 +141,7 @@ inline void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* l
     lo->bwd_zero_end = off;
     lo->g_e[1] = take((size_t)E * 4 * sizeof(float));
     lo->g_h[1] = take((size_t)N * 32 * sizeof(float));
-    lo->g_dz2 = take((size_t)E * 32 * sizeof(float));
+    lo->g_de2 = take((size_t)E * 4 * sizeof(float));
     lo->g_arg = take((size_t)N * 32 * sizeof(int32_t));
     const size_t npad = (size_t)((N + 31) / 32 * 32);
     lo->gA = take((size_t)N * maxd * sizeof(float));

@@ -99,7 +99,7 @@ static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
     bp.arg = x.at<int>(lo.g_arg);
     const int step = r + 1;
     bp.d_logits = (d_logits_steps && step >= first_cls) ? d_logits_steps[step - first_cls] : nullptr;
-    bp.g_dz2 = x.at<float>(lo.g_dz2);
+    bp.g_de2 = x.at<float>(lo.g_de2);
     bp.g_Q = x.at<float>(lo.g_Q) + (size_t)r * N * 32; bp.g_P = x.at<float>(lo.g_P) + (size_t)r * mtmc::kGradRep * N * 8;
     bp.g_e = g_e[cur_e]; bp.g_e_prev = g_e[cur_e ^ 1]; bp.g_e0 = g_e0; bp.bst = bst + (size_t)(2 * r) * bst_block;
     bp.gr_un_w = const_cast<float*>(grads->upd_node.weight); bp.gr_un_b = const_cast<float*>(grads->upd_node.bias);
@@ -107,6 +107,7 @@ static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
     bp.gr_ue_w = const_cast<float*>(grads->upd_edge.weight); bp.gr_ue_b = const_cast<float*>(grads->upd_edge.bias);
     bp.gr_ue_g = const_cast<float*>(grads->upd_edge.gamma); bp.gr_ue_bt = const_cast<float*>(grads->upd_edge.beta);
     bp.gr_cls_w = const_cast<float*>(grads->cls.weight); bp.gr_cls_b = const_cast<float*>(grads->cls.bias);
+    bp.gacc = x.at<float>(lo.gacc);
 
     if (m->agg == MTMC_AGG_MAX) {
       HIP_OK(hipMemsetAsync(bp.arg, 0x7f, (size_t)N * 32 * sizeof(int32_t), s));
@@ -133,6 +134,7 @@ static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
     mtmc::BwdEncParams ep;
     ep.enc = enc_params(x); ep.attr = call->edge_attr; ep.n_edges = E; ep.e_total = (double)E; ep.g_e0 = g_e0;
     ep.bst = bst + (size_t)(2 * L) * bst_block; ep.d_attr = d_edge_attr;
+    ep.gacc = x.at<float>(lo.gacc);
     ep.gr_w1 = const_cast<float*>(grads->enc_edge[0].weight); ep.gr_b1 = const_cast<float*>(grads->enc_edge[0].bias);
     ep.gr_g1 = const_cast<float*>(grads->enc_edge[0].gamma); ep.gr_bt1 = const_cast<float*>(grads->enc_edge[0].beta);
     ep.gr_w2 = const_cast<float*>(grads->enc_edge[1].weight); ep.gr_b2 = const_cast<float*>(grads->enc_edge[1].bias);
@@ -192,6 +194,21 @@ static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
         std::swap(gA, gB);
       }
     }
+  }
+  {  // the replicated small-gradient sums of the edge kernels -> the caller's tensors
+    static_assert(mtmc::kGradRep == 16 && mtmc::kGaccN == 256, "Layout::gacc is sized for 16 x 256 floats");
+    mtmc::GradFoldParams fp;
+    fp.gacc = x.at<float>(lo.gacc);
+    fp.gr_un_w = const_cast<float*>(grads->upd_node.weight); fp.gr_un_b = const_cast<float*>(grads->upd_node.bias);
+    fp.un_ld = m->upd_node.in_dim; fp.un_eoff = hn;
+    fp.gr_ue_w = const_cast<float*>(grads->upd_edge.weight); fp.gr_ue_b = const_cast<float*>(grads->upd_edge.bias);
+    fp.ue_ld = m->upd_edge.in_dim; fp.ue_eoff = 2 * hn; fp.nin = m->reattach_edges ? 8 : 4;
+    fp.gr_cls_w = const_cast<float*>(grads->cls.weight); fp.gr_cls_b = const_cast<float*>(grads->cls.bias);
+    fp.n_classes = m->cls.out_dim;
+    fp.gr_w1 = const_cast<float*>(grads->enc_edge[0].weight); fp.gr_b1 = const_cast<float*>(grads->enc_edge[0].bias);
+    fp.gr_w2 = const_cast<float*>(grads->enc_edge[1].weight); fp.gr_b2 = const_cast<float*>(grads->enc_edge[1].bias);
+    fp.fe = m->enc_edge[0].in_dim;
+    mtmc::launch_grad_fold(fp, s);
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MTMC_E_HIP, "kernel launch failed in backward: %s", hipGetErrorString(e));

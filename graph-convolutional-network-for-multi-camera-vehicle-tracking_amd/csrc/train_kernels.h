@@ -6,6 +6,16 @@ namespace mtmc {
 
 constexpr int kGradRep = 16;   // replicas of the dP accumulator (see bwd_edge_upd_kernel)
 
+// Sums that EVERY workgroup of an edge kernel adds to the same few gradient words (biases, the 4-wide edge columns
+// of the update weights, the classifier, the edge encoder): same-address float atomics serialise in L2 at ~130 ns
+// each, i.e. ~90 us behind a 676-workgroup launch.  They go to one of kGradRep replica rows of a workspace scratch
+// instead (row = workgroup % kGradRep, zeroed with the rest of the backward scratch) and grad_fold_kernel adds the
+// rows into the caller's gradient tensors once, at the end of the backward.
+constexpr int kGaUnB = 0, kGaUnW = 32, kGaClsW = 160, kGaClsB = kGaClsW + 4 * MTMC_MAX_CLASSES,
+              kGaUeB = kGaClsB + MTMC_MAX_CLASSES, kGaUeW = kGaUeB + 4, kGaW2 = kGaUeW + 32, kGaB2 = kGaW2 + 16,
+              kGaW1 = kGaB2 + 4, kGaB1 = kGaW1 + 8, kGaccN = 256;
+static_assert(kGaB1 + 4 <= kGaccN, "gradient scratch row too short");
+
 constexpr int kBwdStrideD = 256;   // doubles per replica of the backward statistics scratch (api_internal.h: kBwdStride)
 
 struct BwdRoundParams {
@@ -15,8 +25,8 @@ struct BwdRoundParams {
   const int* deg;
   int* arg;                  // [N][32] max aggregation: edge index of the arg max per (node, channel)
   const float* d_logits;     // [E][C] gradient of this round's logits, or nullptr
-  float* g_dz2;              // [E][32] scratch: gradient wrt the node-update pre-activation
-  float* g_Q; float* g_P;    // [N][32], [kGradRep][N][8] (zeroed by the host before the round)
+  float* g_de2;              // [E][4] scratch: A^T . (gradient wrt the node-update pre-activation)
+  float* g_Q; float* g_P;    // [N][32], [kGradRep]{dPr [N][4], dPc [4][N]} (zeroed by the host before the round)
   float* g_e;                // [E][4] in: gradient wrt e_r from later rounds; becomes g1 (mode 0 of the edge kernel)
   float* g_e_prev;           // [E][4] out: gradient wrt e_{r-1}
   float* g_e0;               // [E][4] accumulated gradient wrt the encoded edges
@@ -24,6 +34,15 @@ struct BwdRoundParams {
   float* gr_un_w; float* gr_un_b; float* gr_un_g; float* gr_un_bt;
   float* gr_ue_w; float* gr_ue_b; float* gr_ue_g; float* gr_ue_bt;
   float* gr_cls_w; float* gr_cls_b;
+  float* gacc;               // [kGradRep][kGaccN] replicated small-gradient sums (see above)
+};
+
+struct GradFoldParams {
+  const float* gacc;
+  float* gr_un_w; float* gr_un_b; int un_ld, un_eoff;
+  float* gr_ue_w; float* gr_ue_b; int ue_ld, ue_eoff, nin;
+  float* gr_cls_w; float* gr_cls_b; int n_classes;
+  float* gr_w1; float* gr_b1; float* gr_w2; float* gr_b2; int fe;
 };
 
 struct BwdProjParams {
@@ -38,6 +57,7 @@ struct BwdProjParams {
 struct BwdEncParams {
   EdgeEncParams enc; const float* attr; int64_t n_edges; double e_total;
   const float* g_e0; double* bst; float* d_attr;
+  float* gacc;               // [kGradRep][kGaccN]: w1, b1, w2, b2 sums
   float* gr_w1; float* gr_b1; float* gr_g1; float* gr_bt1;
   float* gr_w2; float* gr_b2; float* gr_g2; float* gr_bt2;
 };
@@ -50,6 +70,7 @@ struct BnBwdParams {
 };
 
 void launch_bwd_node_upd(const BwdRoundParams& p, int mode, hipStream_t s);
+void launch_grad_fold(const GradFoldParams& p, hipStream_t s);
 void launch_bwd_edge_upd(const BwdRoundParams& p, int mode, hipStream_t s);
 void launch_bwd_node_proj(const BwdProjParams& p, hipStream_t s);
 void launch_bwd_edge_enc(const BwdEncParams& p, int pass, hipStream_t s);

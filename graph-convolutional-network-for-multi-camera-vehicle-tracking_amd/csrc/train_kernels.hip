@@ -16,6 +16,40 @@
 
 namespace mtmc {
 
+__device__ __forceinline__ void gacc_add(float* gacc, int slot, float v) {
+  unsafeAtomicAdd(gacc + (blockIdx.x % kGradRep) * kGaccN + slot, v);
+}
+
+// The small weights an edge kernel needs for EVERY edge, copied to LDS once per workgroup: read through the parameter
+// struct they are vector loads from global memory that hipcc cannot hoist or make scalar (the kernels store through
+// other pointers), and each one is a memory round trip inside the per-edge code -- 54 `s_waitcnt vmcnt(0)` in
+// bwd_edge_upd_kernel<1>, 32 us for 173k edges before this, against 8 us for the forward pass over the same edges.
+struct EdgeWeightsLds {
+  float w1[8], b1[4], w2[16], b2[4], g1[4], g2[4];     // edge encoder
+  float ue_w[32], ue_g[4];                             // edge-update Linear: its 4 x (4|8) edge columns, BN gamma
+  float cls_w[4 * MTMC_MAX_CLASSES];
+};
+__device__ __forceinline__ void edge_weights_to_lds(const EdgeEncParams& enc, const RoundParams* f, EdgeWeightsLds* w) {
+  const int t = threadIdx.x;
+  if (t < 8) w->w1[t] = t < 4 * enc.fe ? enc.w1[t] : 0.f;
+  else if (t < 12) w->b1[t - 8] = enc.b1[t - 8];
+  else if (t < 28) w->w2[t - 12] = enc.w2[t - 12];
+  else if (t < 32) w->b2[t - 28] = enc.b2[t - 28];
+  else if (t < 36) w->g1[t - 32] = enc.g1[t - 32];
+  else if (t < 40) w->g2[t - 36] = enc.g2[t - 36];
+  else if (f && t >= 64 && t < 96) {
+    const int kk = (t - 64) >> 3, j = (t - 64) & 7;
+    w->ue_w[t - 64] = j < (f->reattach_edges ? 8 : 4) ? f->ue_w[kk * f->ue_ld + f->ue_eoff + j] : 0.f;
+  } else if (f && t >= 96 && t < 100) w->ue_g[t - 96] = f->ue_g[t - 96];
+  else if (f && t >= 128 && t < 128 + 4 * MTMC_MAX_CLASSES)
+    w->cls_w[t - 128] = (t - 128) < 4 * f->n_classes ? f->cls_w[t - 128] : 0.f;
+}
+__device__ __forceinline__ EdgeEncParams enc_from_lds(const EdgeEncParams& enc, const EdgeWeightsLds* w) {
+  EdgeEncParams e = enc;
+  e.w1 = w->w1; e.b1 = w->b1; e.w2 = w->w2; e.b2 = w->b2; e.g1 = w->g1; e.g2 = w->g2;
+  return e;
+}
+
 __device__ __forceinline__ void mean_istd(double sum, double sumsq, double count, float& mu, float& istd) {
   const double inv = 1.0 / count;
   const double mean = sum * inv;
@@ -38,6 +72,10 @@ __global__ __launch_bounds__(256) void bwd_node_upd_kernel(BwdRoundParams p) {
   __shared__ int tile_row[256];
   __shared__ double st[10 + 64 + 64];     // e' second moments | z2 sum, sumsq | (mode 1) sum g, sum g*zh
   __shared__ double red[8 * 32 * 6];
+  // mode 1: dz2 of a half-wave's 32 edges, [edge][channel] with an odd row stride, so that the lanes can swap roles
+  // (channel -> edge) and leave A^T.dz2 (4 floats per edge) instead of the 32-wide dz2 itself
+  __shared__ float dzt[MODE == 1 ? 8 * 32 * 33 : 1];
+  __shared__ float4 a_all[32];
   const int k = threadIdx.x & 31, hw = threadIdx.x >> 5;
   stat_gather(p.f.stats + kRoundMOff + 4, 10, kMStride, st);
   stat_gather(p.f.stats + kRoundZ2Off, 64, kZ2Stride, st + 10);
@@ -47,6 +85,7 @@ __global__ __launch_bounds__(256) void bwd_node_upd_kernel(BwdRoundParams p) {
   float a4[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) a4[j] = aw[j];
+  if (MODE == 1 && hw == 0) a_all[k] = make_float4(a4[0], a4[1], a4[2], a4[3]);
   const float bk = p.f.un_b[k], gam = p.f.un_g[k], bet = p.f.un_bt[k];
   float mu, istd, sk, tk;
   const double z2sq = st[10 + 32 + k] + quad_form(aw, 4, st);
@@ -107,13 +146,26 @@ __global__ __launch_bounds__(256) void bwd_node_upd_kernel(BwdRoundParams p) {
         acc[1] += (double)g * zh;
       } else {
         const float dz2 = gam * istd * (g - mean_g - zh * mean_gz);
-        p.g_dz2[eidx * kH + k] = dz2;
+        dzt[(hw * 32 + j) * 33 + k] = dz2;
         dq_acc += dz2;
         acc[0] += dz2;
         acc[1] += (double)dz2 * v.x; acc[2] += (double)dz2 * v.y; acc[3] += (double)dz2 * v.z; acc[4] += (double)dz2 * v.w;
       }
     }
     if (MODE == 1 && cur >= 0) unsafeAtomicAdd(p.g_Q + (int64_t)cur * kH + k, dq_acc);
+    if (MODE == 1) {
+      __builtin_amdgcn_wave_barrier();               // the half-wave's own LDS writes, read back below by other lanes
+      if (k < n_here) {                              // lane k now stands for edge k of the half-wave's 32
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < 32; ++c) {
+          const float d = dzt[(hw * 32 + k) * 33 + c];
+          const float4 a = a_all[c];
+          d0 = fmaf(a.x, d, d0); d1 = fmaf(a.y, d, d1); d2 = fmaf(a.z, d, d2); d3 = fmaf(a.w, d, d3);
+        }
+        reinterpret_cast<float4*>(p.g_de2)[base + hw * 32 + k] = make_float4(d0, d1, d2, d3);
+      }
+    }
     __syncthreads();
   }
   if (MODE == 2) return;
@@ -129,9 +181,9 @@ __global__ __launch_bounds__(256) void bwd_node_upd_kernel(BwdRoundParams p) {
       if (MODE == 0) {
         unsafeAtomicAdd(p.bst + (blockIdx.x % kStatRep) * kBwdStrideD + i * 32 + k, s);
       } else if (i == 0) {
-        unsafeAtomicAdd(p.gr_un_b + k, (float)s);
+        gacc_add(p.gacc, kGaUnB + k, (float)s);
       } else {
-        unsafeAtomicAdd(p.gr_un_w + k * p.f.un_ld + p.f.un_eoff + (i - 1), (float)s);
+        gacc_add(p.gacc, kGaUnW + k * 4 + (i - 1), (float)s);
       }
     }
     if (MODE == 1 && blockIdx.x == 0) {      // dgamma = sum g*zh, dbeta = sum g (the statistics of mode 0)
@@ -151,8 +203,11 @@ __global__ __launch_bounds__(256) void bwd_edge_upd_kernel(BwdRoundParams p) {
   __shared__ EdgeEncAffine af;
   __shared__ EdgeBwdShared sh;
   __shared__ double red[64 * 4];
+  __shared__ EdgeWeightsLds wl;
   stat_gather(p.f.stats + kRoundZ1Off, 8, kZ1Stride, red);
   if (MODE == 1) stat_gather(p.bst, 8, kBwdStrideD, red + 8);
+  edge_weights_to_lds(p.f.enc, &p.f, &wl);
+  const EdgeEncParams enc = enc_from_lds(p.f.enc, &wl);
   const bool need_e0 = MODE == 1 && (p.f.first_round || p.f.reattach_edges);
   if (need_e0) edge_enc_affine_load(p.f.enc, &af); else __syncthreads();
   if (threadIdx.x < 4) {
@@ -191,12 +246,8 @@ __global__ __launch_bounds__(256) void bwd_edge_upd_kernel(BwdRoundParams p) {
       // total gradient wrt e_r: later rounds (g_e) + node-update path (A^T dz2) + classifier (Wc^T dlogits)
       float4 ge4 = reinterpret_cast<const float4*>(p.g_e)[e];
       float de[4] = {ge4.x, ge4.y, ge4.z, ge4.w};
-      for (int kk = 0; kk < kH; ++kk) {
-        const float d = p.g_dz2[e * kH + kk];
-        const float* aw = p.f.un_w + kk * p.f.un_ld + p.f.un_eoff;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) de[j] = fmaf(aw[j], d, de[j]);
-      }
+      const float4 d2 = reinterpret_cast<const float4*>(p.g_de2)[e];       // A^T dz2, left by bwd_node_upd_kernel<1>
+      de[0] += d2.x; de[1] += d2.y; de[2] += d2.z; de[3] += d2.w;
       if (p.d_logits) {
 #pragma unroll
         for (int c = 0; c < MTMC_MAX_CLASSES; ++c) {     // static indices into acc[]: it must stay in registers
@@ -204,7 +255,7 @@ __global__ __launch_bounds__(256) void bwd_edge_upd_kernel(BwdRoundParams p) {
             const float dl = p.d_logits[e * C + c];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              de[j] = fmaf(p.f.cls_w[c * 4 + j], dl, de[j]);
+              de[j] = fmaf(wl.cls_w[c * 4 + j], dl, de[j]);
               acc[8 + c * 4 + j] += (double)dl * er[j];
             }
             acc[24 + c] += dl;
@@ -224,24 +275,27 @@ __global__ __launch_bounds__(256) void bwd_edge_upd_kernel(BwdRoundParams p) {
       const float g1[4] = {g4.x, g4.y, g4.z, g4.w};
       float dz1[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dz1[j] = p.f.ue_g[j] * sh.istd1[j] * (g1[j] - sh.mean_g[j] - zh[j] * sh.mean_gz[j]);
+      for (int j = 0; j < 4; ++j) dz1[j] = wl.ue_g[j] * sh.istd1[j] * (g1[j] - sh.mean_g[j] - zh[j] * sh.mean_gz[j]);
       const int r = p.f.row32[e], c = p.f.col32[e];
       // dP: ~E/N atomics land on every one of the N*8 addresses and same-address atomics serialise in L2 (measured
       // 53 us of this 62 us kernel); kGradRep replicas by workgroup cut the chains, bwd_node_proj adds them up
       float* gP = p.g_P + (size_t)(blockIdx.x % kGradRep) * p.f.n_nodes * 8;
-      wave_run_atomic_add<4>(dz1, r, active, gP, 8);      // rows come in long runs: reduce in the wave first
+      // replica layout: dPr [N][4], then dPc [4][N] -- the lanes of a wave hold consecutive (or nearly so) columns, so
+      // channel-major puts a wave's 64 column atomics on 2-3 cache lines instead of 16 (17 of this kernel's 34 us were
+      // those scattered atomics)
+      wave_run_atomic_add<4>(dz1, r, active, gP, 4);      // rows come in long runs: reduce in the wave first
       if (!active) continue;
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] += dz1[j];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) unsafeAtomicAdd(gP + (int64_t)c * 8 + 4 + j, dz1[j]);
+      for (int j = 0; j < 4; ++j) unsafeAtomicAdd(gP + (4 + j) * p.f.n_nodes + c, dz1[j]);
       // the edge input of this round: [e0 | e_prev] (reattach) or e_prev, with e_prev = e0 in the first round
       float e0[4] = {0, 0, 0, 0}, ein[8];
       if (p.f.first_round || p.f.reattach_edges) {
         float a0, a1, u[4];
-        load_attr(p.f.attr, p.f.enc.fe, e, a0, a1);
-        edge_enc_hidden(p.f.enc, af, e, a0, a1, u);
-        edge_enc_out(p.f.enc, af, e, u, e0);
+        load_attr(p.f.attr, enc.fe, e, a0, a1);
+        edge_enc_hidden(enc, af, e, a0, a1, u);
+        edge_enc_out(enc, af, e, u, e0);
       }
       float ep[4];
       if (p.f.first_round) {
@@ -260,7 +314,7 @@ __global__ __launch_bounds__(256) void bwd_edge_upd_kernel(BwdRoundParams p) {
           float s = 0.f;
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) {
-            s = fmaf(p.f.ue_w[kk * p.f.ue_ld + p.f.ue_eoff + j], dz1[kk], s);
+            s = fmaf(wl.ue_w[kk * 8 + j], dz1[kk], s);
             acc[4 + kk * 8 + j] += (double)dz1[kk] * ein[j];
           }
           din[j] = s;
@@ -299,13 +353,13 @@ __global__ __launch_bounds__(256) void bwd_edge_upd_kernel(BwdRoundParams p) {
     const double s = red[i] + red[64 + i] + red[128 + i] + red[192 + i];
     if (MODE == 0) {
       if (i < 8) unsafeAtomicAdd(p.bst + (blockIdx.x % kStatRep) * kBwdStrideD + i, s);
-      else if (i < 24) { if ((i - 8) / 4 < C) unsafeAtomicAdd(p.gr_cls_w + (i - 8), (float)s); }
-      else if (i - 24 < C) unsafeAtomicAdd(p.gr_cls_b + (i - 24), (float)s);
+      else if (i < 24) { if ((i - 8) / 4 < C) gacc_add(p.gacc, kGaClsW + (i - 8), (float)s); }
+      else if (i - 24 < C) gacc_add(p.gacc, kGaClsB + (i - 24), (float)s);
     } else {
-      if (i < 4) unsafeAtomicAdd(p.gr_ue_b + i, (float)s);
+      if (i < 4) gacc_add(p.gacc, kGaUeB + i, (float)s);
       else {
         const int kk = (i - 4) / 8, j = (i - 4) % 8;
-        if (j < nin) unsafeAtomicAdd(p.gr_ue_w + kk * p.f.ue_ld + p.f.ue_eoff + j, (float)s);
+        if (j < nin) gacc_add(p.gacc, kGaUeW + kk * 8 + j, (float)s);
       }
     }
   }
@@ -345,7 +399,8 @@ __global__ __launch_bounds__(256) void bwd_node_proj_kernel(BwdProjParams p) {
       if (node < p.n_nodes) {
         if (j < 8) {
 #pragma unroll
-          for (int rep = 0; rep < kGradRep; ++rep) v += p.g_P[(size_t)rep * p.n_nodes * 8 + node * 8 + j];
+          for (int rep = 0; rep < kGradRep; ++rep)
+            v += p.g_P[(size_t)rep * p.n_nodes * 8 + (j < 4 ? node * 4 + j : (size_t)j * p.n_nodes + node)];
         } else {
           v = p.g_Q[node * kH + j - 8];
         }
@@ -406,6 +461,8 @@ __global__ __launch_bounds__(256) void bwd_edge_enc_kernel(BwdEncParams p) {
   __shared__ EncBwdShared sh;
   __shared__ double sc[kStatAttr + kStatEnc2 + 16];
   __shared__ double red[64 * 4];
+  __shared__ EdgeWeightsLds wl;
+  edge_weights_to_lds(p.enc, nullptr, &wl);                       // (the first barrier below publishes it)
   edge_enc_affine_to_smem(p.enc, p.e_total, 2, &af, sc);          // also leaves the summed moments in sc
   if (PASS >= 1) stat_gather(p.bst, 8, kBwdStrideD, sc + kStatAttr + kStatEnc2);
   if (PASS >= 2) stat_gather(p.bst + 8, 8, kBwdStrideD, sc + kStatAttr + kStatEnc2 + 8);
@@ -434,17 +491,17 @@ __global__ __launch_bounds__(256) void bwd_edge_enc_kernel(BwdEncParams p) {
     load_attr(p.attr, fe, e, a0, a1);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      float z = p.enc.b1[k] + p.enc.w1[k * fe] * a0;
-      if (fe > 1) z = fmaf(p.enc.w1[k * fe + 1], a1, z);
+      float z = wl.b1[k] + wl.w1[k * fe] * a0;
+      if (fe > 1) z = fmaf(wl.w1[k * fe + 1], a1, z);
       za[k] = z;
       zha[k] = (z - sh.mua[k]) * sh.ia[k];
       u[k] = drop_apply(p.enc.drop, kDropEncEdge1, (unsigned long long)e * 4 + k, fmaxf(fmaf(z, af.s1[k], af.t1[k]), 0.f));
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      float z = p.enc.b2[k];
+      float z = wl.b2[k];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) z = fmaf(p.enc.w2[k * 4 + j], u[j], z);
+      for (int j = 0; j < 4; ++j) z = fmaf(wl.w2[k * 4 + j], u[j], z);
       zb[k] = z;
       zhb[k] = (z - sh.mub[k]) * sh.ib[k];
       e0[k] = drop_apply(p.enc.drop, kDropEncEdge2, (unsigned long long)e * 4 + k, fmaxf(fmaf(z, af.s2[k], af.t2[k]), 0.f));
@@ -461,11 +518,11 @@ __global__ __launch_bounds__(256) void bwd_edge_enc_kernel(BwdEncParams p) {
     }
     float dzb[4], du[4] = {0, 0, 0, 0}, ga[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) dzb[k] = p.enc.g2[k] * sh.ib[k] * (gb[k] - sh.mgb[k] - zhb[k] * sh.mgzb[k]);
+    for (int k = 0; k < 4; ++k) dzb[k] = wl.g2[k] * sh.ib[k] * (gb[k] - sh.mgb[k] - zhb[k] * sh.mgzb[k]);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) du[j] = fmaf(p.enc.w2[k * 4 + j], dzb[k], du[j]);
+      for (int k = 0; k < 4; ++k) du[j] = fmaf(wl.w2[k * 4 + j], dzb[k], du[j]);
 #pragma unroll
     for (int k = 0; k < 4; ++k) ga[k] = u[k] > 0.f ? du[k] * ik : 0.f;
     if (PASS == 1) {
@@ -482,7 +539,7 @@ __global__ __launch_bounds__(256) void bwd_edge_enc_kernel(BwdEncParams p) {
     float dza[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      dza[k] = p.enc.g1[k] * sh.ia[k] * (ga[k] - sh.mga[k] - zha[k] * sh.mgza[k]);
+      dza[k] = wl.g1[k] * sh.ia[k] * (ga[k] - sh.mga[k] - zha[k] * sh.mgza[k]);
       acc[8 + k] += dza[k];
       acc[k * 2] += (double)dza[k] * a0;
       acc[k * 2 + 1] += (double)dza[k] * a1;
@@ -490,7 +547,7 @@ __global__ __launch_bounds__(256) void bwd_edge_enc_kernel(BwdEncParams p) {
     if (p.d_attr) {
       float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { s0 = fmaf(p.enc.w1[k * fe], dza[k], s0); if (fe > 1) s1 = fmaf(p.enc.w1[k * fe + 1], dza[k], s1); }
+      for (int k = 0; k < 4; ++k) { s0 = fmaf(wl.w1[k * fe], dza[k], s0); if (fe > 1) s1 = fmaf(wl.w1[k * fe + 1], dza[k], s1); }
       p.d_attr[e * fe] = s0;
       if (fe > 1) p.d_attr[e * fe + 1] = s1;
     }
@@ -509,11 +566,11 @@ __global__ __launch_bounds__(256) void bwd_edge_enc_kernel(BwdEncParams p) {
     if (PASS == 0) unsafeAtomicAdd(p.bst + (blockIdx.x % kStatRep) * kBwdStrideD + i, s);
     else if (PASS == 1) {
       if (i < 8) unsafeAtomicAdd(p.bst + (blockIdx.x % kStatRep) * kBwdStrideD + 8 + i, s);
-      else if (i < 24) unsafeAtomicAdd(p.gr_w2 + (i - 8), (float)s);
-      else unsafeAtomicAdd(p.gr_b2 + (i - 24), (float)s);
+      else if (i < 24) gacc_add(p.gacc, kGaW2 + (i - 8), (float)s);
+      else gacc_add(p.gacc, kGaB2 + (i - 24), (float)s);
     } else {
-      if (i < 8) { if ((i & 1) < fe) unsafeAtomicAdd(p.gr_w1 + (i >> 1) * fe + (i & 1), (float)s); }
-      else unsafeAtomicAdd(p.gr_b1 + (i - 8), (float)s);
+      if (i < 8) { if ((i & 1) < fe) gacc_add(p.gacc, kGaW1 + i, (float)s); }
+      else gacc_add(p.gacc, kGaB1 + (i - 8), (float)s);
     }
   }
   if (blockIdx.x == 0 && threadIdx.x < 4) {
@@ -528,12 +585,14 @@ __global__ __launch_bounds__(256) void bwd_edge_enc_kernel(BwdEncParams p) {
 // ------------------------------------------------------------------------------------------------
 // column statistics of g = (a > 0 ? dA/keep : 0) against zh = (Y-mu)*istd: stats[0..d) = sum g, [d..2d) = sum g*zh;
 // MODE 1: dY = gamma*istd*(g - mean_g - zh*mean_gz) written over dA, and column sums of dY -> d_bias
+constexpr int kBnBwdRows = 16;   // rows per workgroup: a few hundred node rows must still spread over the chip (64 rows
+                                 // per workgroup: 12.4 / 8.1 us per launch at 430 x 1024)
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p) {
   __shared__ double red[2 * 4 * 64];
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cl;
-  const int64_t r0 = (int64_t)blockIdx.y * 64;
+  const int64_t r0 = (int64_t)blockIdx.y * kBnBwdRows;
   double s0 = 0, s1 = 0;
   if (col < p.dim) {
     float mu, istd;
@@ -542,7 +601,10 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p) {
     const float ik = p.drop.on ? p.drop.inv_keep : 1.f;
     const float mg = MODE == 1 ? (float)(p.stats_bwd[col] / p.count) : 0.f;
     const float mgz = MODE == 1 ? (float)(p.stats_bwd[p.dim + col] / p.count) : 0.f;
-    for (int64_t row = r0 + rg; row < r0 + 64 && row < p.rows; row += 4) {
+#pragma unroll
+    for (int i = 0; i < kBnBwdRows / 4; ++i) {
+      const int64_t row = r0 + rg + 4 * i;
+      if (row >= p.rows) break;
       const float zh = (p.Y[row * p.dim + col] - mu) * istd;
       const float y = fmaf(gam, zh, bet);
       const bool live = y > 0.f && drop_keep(p.drop, p.drop_stream, (unsigned long long)row * p.dim + col);
@@ -598,6 +660,30 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* src, in
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+// the replicated small-gradient sums -> the caller's gradient tensors (one workgroup, the last launch of the backward;
+// plain += : nothing else touches these words any more, the node-column blocks of the update weights are other words)
+__global__ __launch_bounds__(256) void grad_fold_kernel(GradFoldParams p) {
+  const int i = threadIdx.x;
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < kGradRep; ++r) s += p.gacc[r * kGaccN + i];
+  float* dst = nullptr;
+  if (i < kGaUnW) dst = p.gr_un_b + i;
+  else if (i < kGaClsW) dst = p.gr_un_w + ((i - kGaUnW) >> 2) * p.un_ld + p.un_eoff + ((i - kGaUnW) & 3);
+  else if (i < kGaClsB) { if ((i - kGaClsW) / 4 < p.n_classes) dst = p.gr_cls_w + (i - kGaClsW); }
+  else if (i < kGaUeB) { if (i - kGaClsB < p.n_classes) dst = p.gr_cls_b + (i - kGaClsB); }
+  else if (i < kGaUeW) dst = p.gr_ue_b + (i - kGaUeB);
+  else if (i < kGaW2) { const int kk = (i - kGaUeW) >> 3, j = (i - kGaUeW) & 7; if (j < p.nin) dst = p.gr_ue_w + kk * p.ue_ld + p.ue_eoff + j; }
+  else if (i < kGaB2) dst = p.gr_w2 + (i - kGaW2);
+  else if (i < kGaW1) dst = p.gr_b2 + (i - kGaB2);
+  else if (i < kGaB1) { const int q = i - kGaW1; if ((q & 1) < p.fe) dst = p.gr_w1 + (q >> 1) * p.fe + (q & 1); }
+  else if (i < kGaB1 + 4) dst = p.gr_b1 + (i - kGaB1);
+  if (dst) *dst += s;
+}
+void launch_grad_fold(const GradFoldParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(grad_fold_kernel, dim3(1), dim3(kGaccN), 0, s, p);
+}
+
 static inline int cap(int64_t blocks, int64_t hi = 1024) { return (int)(blocks < 1 ? 1 : (blocks > hi ? hi : blocks)); }
 
 void launch_bwd_node_upd(const BwdRoundParams& p, int mode, hipStream_t s) {
@@ -676,7 +762,7 @@ void launch_bwd_edge_enc(const BwdEncParams& p, int pass, hipStream_t s) {
   else hipLaunchKernelGGL(bwd_edge_enc_kernel<2>, dim3(grid), dim3(256), 0, s, p);
 }
 void launch_bn_bwd(const BnBwdParams& p, int mode, hipStream_t s) {
-  const dim3 grid((p.dim + 63) / 64, (unsigned)((p.rows + 63) / 64));
+  const dim3 grid((p.dim + 63) / 64, (unsigned)((p.rows + kBnBwdRows - 1) / kBnBwdRows));
   if (mode == 0) hipLaunchKernelGGL(bn_bwd_kernel<0>, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(bn_bwd_kernel<1>, grid, dim3(256), 0, s, p);
 }
