@@ -40,6 +40,7 @@ struct Layout {
   size_t bst;                                  // f64[2L+1][kStatRep][kBwdStride] backward statistics blocks
   size_t bwd_zero, bwd_zero_end;               // the range the backward clears with one memset
   size_t gacc;                                 // f32[kGradRep][kGaccN] (train_kernels.h)
+  size_t amax_bwd;                             // u32[2][MTMC_MAX_ENC_LAYERS][kAmaxRep] (zeroed with the backward scratch)
   size_t gA, gB, tA, tB, tW, zeros, bst_n;     // node-encoder backward: gradient ping-pong, transposes, 0-bias, column stats
 };
 constexpr int kBwdStride = 256;                // doubles per replica of the backward statistics scratch
@@ -131,6 +132,7 @@ inline void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* l
     lo->bst = take((size_t)(2 * L + 1) * mtmc::kStatRep * kBwdStride * sizeof(double));   // per round: node, edge; + encoder
     lo->bst_n = take(bn_stats * sizeof(double));
     lo->gacc = take((size_t)16 * 256 * sizeof(float));                   // [kGradRep][kGaccN] small-gradient replicas
+    lo->amax_bwd = take((size_t)2 * MTMC_MAX_ENC_LAYERS * mtmc::kAmaxRep * sizeof(uint32_t));   // |dY_l|max, |a_{l-1}|max
     lo->g_P = take((size_t)(L > 0 ? L : 1) * 16 * N * 8 * sizeof(float)); // per round: [kGradRep = 16][N][8]
     lo->g_Q = take((size_t)(L > 0 ? L : 1) * N * 32 * sizeof(float));     // per round
     lo->zeros = take(maxd * sizeof(float));

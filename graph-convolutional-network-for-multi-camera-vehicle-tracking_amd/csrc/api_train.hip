@@ -167,6 +167,12 @@ static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
       bb.gamma = Lr.gamma; bb.beta = Lr.beta; bb.drop = make_drop(x, m->dropout_enc); bb.drop_stream = mtmc::kDropEncNode + l;
       bb.gr_gamma = const_cast<float*>(grads->enc_node[l].gamma); bb.gr_beta = const_cast<float*>(grads->enc_node[l].beta);
       bb.gr_bias = const_cast<float*>(grads->enc_node[l].bias);
+      // |.|max of the three GEMM operands of this layer: dY_l (written by bn_bwd's apply pass), a_{l-1} (x: the forward's
+      // value; else from the recomputation below) and W_l (the forward's) -> the fp16 three-product kernel applies
+      unsigned* amax_fwd = x.at<unsigned>(lo.amax);
+      unsigned* amax_dy = x.at<unsigned>(lo.amax_bwd) + (size_t)l * mtmc::kAmaxRep;
+      unsigned* amax_act = x.at<unsigned>(lo.amax_bwd) + (size_t)(MTMC_MAX_ENC_LAYERS + l) * mtmc::kAmaxRep;
+      bb.amax_out = amax_dy;
       mtmc::launch_bn_bwd(bb, 0, s);
       mtmc::launch_bn_bwd(bb, 1, s);                                   // gA now holds dY_l
       // the layer's input activation a_{l-1}: x itself, or relu(bn(Y_{l-1})) with its dropout mask
@@ -175,7 +181,8 @@ static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
       if (l > 0) {
         const mtmc_layer& Pv = m->enc_node[l - 1];
         mtmc::launch_bn_relu_rows(x.at<float>(lo.Y[l - 1]), Pv.out_dim, N, Pv.out_dim, x.at<double>(lo.stat_enc_layer[l - 1]),
-                                  Pv.gamma, Pv.beta, (double)N, gB, make_drop(x, m->dropout_enc), mtmc::kDropEncNode + l - 1, 0, s);
+                                  Pv.gamma, Pv.beta, (double)N, gB, make_drop(x, m->dropout_enc), mtmc::kDropEncNode + l - 1, 0, s,
+                                  amax_act);
         a_in = gB; lda = in;
       }
       // dW_l [d][in] = dY^T . a  -> NT GEMM on the transposes (reduction over the node rows, padded to 32)
@@ -185,11 +192,13 @@ static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
       g.A = tA; g.lda = npad; g.W = tB; g.bias = zeros; g.Y = const_cast<float*>(grads->enc_node[l].weight); g.ldy = in;
       g.stats_in = nullptr; g.gamma_in = nullptr; g.beta_in = nullptr; g.count = 1; g.stats_out = nullptr;
       g.M = d; g.K = (int)npad; g.Nout = in; g.drop_in = nodrop; g.drop_stream = 0; g.slab = nullptr; g.split_k = 1;
+      g.amax_a = amax_dy; g.amax_w = l > 0 ? amax_act : amax_fwd; g.amax_y = nullptr;
       if (mtmc::launch_gemm_bn(g, s) != MTMC_OK) return fail(MTMC_E_ARG, "backward: weight-gradient GEMM shape");
       // dA_{l-1} [N][in] = dY . W_l  -> NT GEMM against W^T
       if (l > 0 || d_x) {
         mtmc::launch_transpose_pad(Lr.weight, d, in, in, tW, d, s);   // tW [in][d]
         g.A = gA; g.lda = d; g.W = tW; g.Y = l > 0 ? gB : d_x; g.ldy = in; g.M = N; g.K = d; g.Nout = in;
+        g.amax_w = amax_fwd + (size_t)(1 + l) * mtmc::kAmaxRep;
         if (mtmc::launch_gemm_bn(g, s) != MTMC_OK) return fail(MTMC_E_ARG, "backward: input-gradient GEMM shape");
         std::swap(gA, gB);
       }

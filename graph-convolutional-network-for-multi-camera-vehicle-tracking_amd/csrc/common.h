@@ -113,6 +113,13 @@ __device__ __forceinline__ void wave_run_atomic_add(const float (&vin)[NV], int 
   }
 }
 
+// |.|max bookkeeping from many workgroups: same-address atomics serialise in L2 (~130 ns each), so look first -- a
+// stale (lower) value only costs an atomic that was not needed
+__device__ __forceinline__ void amax_publish(unsigned* slot, float v) {
+  const unsigned bits = __float_as_uint(v);
+  if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+}
+
 // dst[i] = sum over replicas of src[r*stride + i], i < n  (cooperative; caller synchronises afterwards)
 __device__ __forceinline__ void stat_gather(const double* src, int n, int stride, double* dst) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) {

@@ -67,6 +67,7 @@ struct BnBwdParams {
   const double* stats_fwd; double* stats_bwd; double count;
   const float* gamma; const float* beta; Drop drop; unsigned drop_stream;
   float* gr_gamma; float* gr_beta; float* gr_bias;
+  unsigned* amax_out;        // u32[kAmaxRep] |dY|max (mode 1; atomicMax on the bit patterns), or nullptr
 };
 
 void launch_bwd_node_upd(const BwdRoundParams& p, int mode, hipStream_t s);

@@ -594,6 +594,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p) {
   const int col = blockIdx.x * 64 + cl;
   const int64_t r0 = (int64_t)blockIdx.y * kBnBwdRows;
   double s0 = 0, s1 = 0;
+  float dymax = 0.f;
   if (col < p.dim) {
     float mu, istd;
     mean_istd(p.stats_fwd[col], p.stats_fwd[p.dim + col], p.count, mu, istd);
@@ -615,6 +616,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p) {
       } else {
         const float dy = gam * istd * (g - mg - zh * mgz);
         p.dA[row * p.dim + col] = dy;
+        dymax = fmaxf(dymax, fabsf(dy));
         s0 += dy;
       }
     }
@@ -630,6 +632,15 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p) {
       if (MODE == 0) unsafeAtomicAdd(p.stats_bwd + which * p.dim + c, s);
       else if (which == 0) unsafeAtomicAdd(p.gr_bias + c, (float)s);
     }
+  }
+  if (MODE == 1 && p.amax_out) {                   // operand scale of the weight- / input-gradient GEMMs
+    __shared__ float wmax[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dymax = fmaxf(dymax, __shfl_xor(dymax, off, 64));
+    if (cl == 0) wmax[rg] = dymax;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      amax_publish(p.amax_out + (blockIdx.x + blockIdx.y) % kAmaxRep, fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
   }
   if (MODE == 1 && blockIdx.y == 0 && threadIdx.x < 64 && col < p.dim) {
     p.gr_gamma[col] = (float)p.stats_bwd[p.dim + col];
