@@ -36,6 +36,7 @@ struct Layout {
   // training: every round keeps its own buffers (the workspace is the backward tape) + backward scratch
   bool training;
   std::vector<size_t> z_tr, e_tr, h_tr;       // per round: z1 [E][4], e' [E][4], aggregated h [N][32]
+  std::vector<size_t> P_tr, Q_tr;             // per round: the node projections [2][N][4], [N][32]
   size_t g_e[2], g_e0, g_h[2], g_h0, g_P, g_Q, g_de2, g_arg;   // gradients wrt e_r, e0, h_r, h0, P, Q; A^T dz2 [E][4]
   size_t bst;                                  // f64[2L+1][kStatRep][kBwdStride] backward statistics blocks
   size_t bwd_zero, bwd_zero_end;               // the range the backward clears with one memset
@@ -120,6 +121,8 @@ inline void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* l
       lo->z_tr.push_back(take((size_t)E * 4 * sizeof(float)));
       lo->e_tr.push_back(take((size_t)E * 4 * sizeof(float)));
       lo->h_tr.push_back(take((size_t)N * 32 * sizeof(float)));
+      lo->P_tr.push_back(r == 0 ? lo->P : take((size_t)N * 8 * sizeof(float)));     // the round's projections stay on the
+      lo->Q_tr.push_back(r == 0 ? lo->Q : take((size_t)N * 32 * sizeof(float)));    // tape: the backward reads them as is
     }
     // everything the backward accumulates into, contiguous: ONE memset clears it (api_train.hip)
     size_t maxd = 0, bn_stats = 0;
@@ -226,6 +229,8 @@ inline float* round_h_src(const Ctx& x, int r) {
   if (r == 0) return x.at<float>(x.lo.pub.h0_off);
   return x.lo.training ? x.at<float>(x.lo.h_tr[r - 1]) : x.at<float>(x.lo.pub.h_acc_off[(r - 1) & 1]);
 }
+inline float* round_P(const Ctx& x, int r) { return x.at<float>(x.lo.training ? x.lo.P_tr[r] : x.lo.P); }
+inline float* round_Q(const Ctx& x, int r) { return x.at<float>(x.lo.training ? x.lo.Q_tr[r] : x.lo.Q); }
 inline float* round_z(const Ctx& x, int r) { return x.at<float>(x.lo.training ? x.lo.z_tr[r] : x.lo.e_buf[r & 1]); }
 inline float* round_e(const Ctx& x, int r) { return x.at<float>(x.lo.training ? x.lo.e_tr[r] : x.lo.e_buf[r & 1]); }
 
@@ -238,7 +243,7 @@ inline mtmc::RoundParams round_params(const Ctx& x, int r) {
   p.e_buf = round_z(x, r); p.e_out = round_e(x, r); p.e_prev = r > 0 ? round_e(x, r - 1) : nullptr;
   p.drop_e = make_drop(x, m->dropout_upd_edge); p.drop_n = make_drop(x, m->dropout_upd_node);
   p.drop_stream = mtmc::kDropRound + 2 * r;
-  p.P = x.at<float>(x.lo.P); p.Q = x.at<float>(x.lo.Q);
+  p.P = round_P(x, r); p.Q = round_Q(x, r);
   p.ue_w = m->upd_edge.weight; p.ue_b = m->upd_edge.bias; p.ue_g = m->upd_edge.gamma; p.ue_bt = m->upd_edge.beta;
   p.ue_ld = m->upd_edge.in_dim; p.ue_eoff = 2 * hn;
   p.un_w = m->upd_node.weight; p.un_b = m->upd_node.bias; p.un_g = m->upd_node.gamma; p.un_bt = m->upd_node.beta;
@@ -362,7 +367,7 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
       p.ue_w = m->upd_edge.weight; p.ue_ld = m->upd_edge.in_dim;
       p.un_w = m->upd_node.weight; p.un_ld = m->upd_node.in_dim;
       p.hn = (m->reattach_nodes ? 2 : 1) * MTMC_NODE_DIM;
-      p.P = x.at<float>(x.lo.P); p.Q = x.at<float>(x.lo.Q);
+      p.P = round_P(x, arg); p.Q = round_Q(x, arg);
       p.zero_buf = agg_target(x, arg);
       p.n_nodes = c->n_nodes;
       mtmc::launch_node_proj(p, s);
@@ -382,7 +387,7 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
     case MTMC_PH_ROUND_STAT: {
       if (arg < 0 || arg >= L) return fail(MTMC_E_ARG, "round %d out of range", arg);
       mtmc::NodeStatParams p;
-      p.Q = x.at<float>(x.lo.Q); p.deg = x.at<int>(x.lo.pub.deg_off); p.seg = x.at<double>(x.lo.pub.seg_off);
+      p.Q = round_Q(x, arg); p.deg = x.at<int>(x.lo.pub.deg_off); p.seg = x.at<double>(x.lo.pub.seg_off);
       p.un_w = m->upd_node.weight; p.un_b = m->upd_node.bias; p.un_ld = m->upd_node.in_dim;
       p.un_eoff = (m->reattach_nodes ? 2 : 1) * MTMC_NODE_DIM;
       p.stats = x.at<double>(x.lo.pub.stat_round_off) + (size_t)arg * mtmc::kRoundBlock;

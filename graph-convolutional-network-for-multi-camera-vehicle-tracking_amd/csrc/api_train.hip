@@ -81,17 +81,10 @@ static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
   if (first_cls < 1) first_cls = 1;
 
   for (int r = L - 1; r >= 0; --r) {
-    // P, Q of this round again (same kernel as the forward; h0 and the round inputs are on the tape)
-    mtmc::NodeProjParams np;
-    np.y_last = nullptr; np.y_stats = nullptr; np.y_gamma = nullptr; np.y_beta = nullptr; np.y_count = 1; np.h0_out = nullptr;
-    np.finalize_enc = 0; np.enc = enc_params(x); np.e_total = (double)E;
-    np.drop = make_drop(x, 0.f); np.drop_stream = 0;
-    np.h_src = round_h_src(x, r);
-    np.h0 = m->reattach_nodes ? x.at<float>(lo.pub.h0_off) : nullptr;
-    np.deg = (m->agg == MTMC_AGG_MEAN && r > 0) ? x.at<int>(lo.pub.deg_off) : nullptr;
-    np.ue_w = m->upd_edge.weight; np.ue_ld = m->upd_edge.in_dim; np.un_w = m->upd_node.weight; np.un_ld = m->upd_node.in_dim;
-    np.hn = hn; np.P = x.at<float>(lo.P); np.Q = x.at<float>(lo.Q); np.zero_buf = nullptr; np.n_nodes = N;
-    mtmc::launch_node_proj(np, s);
+    // P, Q of this round are on the tape (Layout::P_tr / Q_tr); what bwd_node_proj needs of the forward's node_proj:
+    const float* h_src_r = round_h_src(x, r);
+    const float* h0_r = m->reattach_nodes ? x.at<float>(lo.pub.h0_off) : nullptr;
+    const int* deg_r = (m->agg == MTMC_AGG_MEAN && r > 0) ? x.at<int>(lo.pub.deg_off) : nullptr;
 
     mtmc::BwdRoundParams bp;
     bp.f = round_params(x, r);
@@ -120,8 +113,9 @@ static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
     mtmc::launch_bwd_edge_upd(bp, 1, s);
 
     mtmc::BwdProjParams pp;
-    pp.g_P = bp.g_P; pp.g_Q = bp.g_Q; pp.h_src = np.h_src; pp.h0 = np.h0; pp.deg = np.deg;
-    pp.ue_w = np.ue_w; pp.ue_ld = np.ue_ld; pp.un_w = np.un_w; pp.un_ld = np.un_ld; pp.hn = hn;
+    pp.g_P = bp.g_P; pp.g_Q = bp.g_Q; pp.h_src = h_src_r; pp.h0 = h0_r; pp.deg = deg_r;
+    pp.ue_w = m->upd_edge.weight; pp.ue_ld = m->upd_edge.in_dim; pp.un_w = m->upd_node.weight; pp.un_ld = m->upd_node.in_dim;
+    pp.hn = hn;
     pp.g_h_prev = g_h[cur ^ 1]; pp.g_h0 = g_h0; pp.src_is_h0 = r == 0;
     pp.gr_ue_w = bp.gr_ue_w; pp.gr_un_w = bp.gr_un_w; pp.n_nodes = N;
     mtmc::launch_bwd_node_proj(pp, s);
