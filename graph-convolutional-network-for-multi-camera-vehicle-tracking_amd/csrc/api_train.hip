@@ -167,6 +167,7 @@ static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
       unsigned* amax_dy = x.at<unsigned>(lo.amax_bwd) + (size_t)l * mtmc::kAmaxRep;
       unsigned* amax_act = x.at<unsigned>(lo.amax_bwd) + (size_t)(MTMC_MAX_ENC_LAYERS + l) * mtmc::kAmaxRep;
       bb.amax_out = amax_dy;
+      bb.dT = tA; bb.ldt = npad;                                       // dY_l^T comes out of the apply pass directly
       mtmc::launch_bn_bwd(bb, 0, s);
       mtmc::launch_bn_bwd(bb, 1, s);                                   // gA now holds dY_l
       // the layer's input activation a_{l-1}: x itself, or relu(bn(Y_{l-1})) with its dropout mask
@@ -176,12 +177,12 @@ static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
         const mtmc_layer& Pv = m->enc_node[l - 1];
         mtmc::launch_bn_relu_rows(x.at<float>(lo.Y[l - 1]), Pv.out_dim, N, Pv.out_dim, x.at<double>(lo.stat_enc_layer[l - 1]),
                                   Pv.gamma, Pv.beta, (double)N, gB, make_drop(x, m->dropout_enc), mtmc::kDropEncNode + l - 1, 0, s,
-                                  amax_act);
+                                  amax_act, tB, npad);               // ... and a_{l-1}^T out of its recomputation
         a_in = gB; lda = in;
+      } else {
+        mtmc::launch_transpose_pad(a_in, N, in, lda, tB, npad, s);     // x^T
       }
       // dW_l [d][in] = dY^T . a  -> NT GEMM on the transposes (reduction over the node rows, padded to 32)
-      mtmc::launch_transpose_pad(gA, N, d, d, tA, npad, s);
-      mtmc::launch_transpose_pad(a_in, N, in, lda, tB, npad, s);
       mtmc::GemmParams g;
       g.A = tA; g.lda = npad; g.W = tB; g.bias = zeros; g.Y = const_cast<float*>(grads->enc_node[l].weight); g.ldy = in;
       g.stats_in = nullptr; g.gamma_in = nullptr; g.beta_in = nullptr; g.count = 1; g.stats_out = nullptr;

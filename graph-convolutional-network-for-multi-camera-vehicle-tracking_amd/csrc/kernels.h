@@ -113,7 +113,8 @@ void launch_node_stat(const NodeStatParams& p, hipStream_t s);
 // h_dst[i][k] = relu(s_k * Y[i][k] + t_k) for local rows; stats over `count` rows
 void launch_bn_relu_rows(const float* Y, int64_t ldy, int64_t rows, int dim, const double* stats, const float* gamma,
                          const float* beta, double count, float* dst, Drop drop, unsigned drop_stream, int64_t row0,
-                         hipStream_t s, unsigned* amax_out = nullptr);   // amax_out: u32[kAmaxRep] |dst|max (atomicMax) or nullptr
+                         hipStream_t s, unsigned* amax_out = nullptr,    // amax_out: u32[kAmaxRep] |dst|max (atomicMax) or nullptr
+                         float* dstT = nullptr, int64_t ldt = 0);         // dstT: dst^T [dim][ldt] as well, rows..ldt zero-filled
 // dst = src (sum/max) or src / max(deg,1) (mean)
 void launch_h_final(const float* src, const int* deg, int mean, int64_t n_nodes, float* dst, hipStream_t s);
 

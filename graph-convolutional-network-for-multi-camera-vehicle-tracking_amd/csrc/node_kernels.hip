@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void node_stat_kernel(NodeStatParams p) {
 __global__ __launch_bounds__(256) void bn_relu_rows_kernel(const float* Y, int64_t ldy, int64_t rows, int dim,
                                                            const double* stats, const float* gamma, const float* beta,
                                                            double count, float* dst, Drop drop, unsigned drop_stream,
-                                                           int64_t row0, unsigned* amax_out) {
+                                                           int64_t row0, unsigned* amax_out, float* dstT, int64_t ldt) {
   const int64_t total = rows * dim;
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
   float vmax = 0.f;
@@ -128,8 +128,12 @@ __global__ __launch_bounds__(256) void bn_relu_rows_kernel(const float* Y, int64
     bn_affine(stats[c], stats[dim + c], count, gamma[c], beta[c], s, t);
     const float v = drop_apply(drop, drop_stream, (unsigned long long)(row0 + r) * dim + c, fmaxf(fmaf(Y[r * ldy + c], s, t), 0.f));
     dst[i] = v;
+    if (dstT) dstT[(int64_t)c * ldt + r] = v;
     vmax = fmaxf(vmax, v);
   }
+  if (dstT)                                          // padding rows of the transposed copy
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (ldt - rows) * dim; i += nthreads)
+      dstT[(i % dim) * ldt + rows + i / dim] = 0.f;
   if (amax_out) {                                  // (backward: operand scale of the weight-gradient GEMM)
     __shared__ float wmax[4];
 #pragma unroll
@@ -162,11 +166,11 @@ void launch_node_stat(const NodeStatParams& p, hipStream_t s) {
 }
 void launch_bn_relu_rows(const float* Y, int64_t ldy, int64_t rows, int dim, const double* stats, const float* gamma,
                          const float* beta, double count, float* dst, Drop drop, unsigned drop_stream, int64_t row0,
-                         hipStream_t s, unsigned* amax_out) {
+                         hipStream_t s, unsigned* amax_out, float* dstT, int64_t ldt) {
   // with the |.|max bookkeeping: one workgroup per CU, so that at most 16 of them meet on a word
   const int64_t blocks = (rows * dim + 255) / 256;
   hipLaunchKernelGGL(bn_relu_rows_kernel, dim3(amax_out && blocks > 256 ? 256 : cap_grid(blocks)), dim3(256), 0, s, Y, ldy,
-                     rows, dim, stats, gamma, beta, count, dst, drop, drop_stream, row0, amax_out);
+                     rows, dim, stats, gamma, beta, count, dst, drop, drop_stream, row0, amax_out, dstT, ldt);
 }
 void launch_h_final(const float* src, const int* deg, int mean, int64_t n_nodes, float* dst, hipStream_t s) {
   hipLaunchKernelGGL(h_final_kernel, dim3(cap_grid((n_nodes * kH + 255) / 256)), dim3(256), 0, s, src, deg, mean,

@@ -68,6 +68,7 @@ struct BnBwdParams {
   const float* gamma; const float* beta; Drop drop; unsigned drop_stream;
   float* gr_gamma; float* gr_beta; float* gr_bias;
   unsigned* amax_out;        // u32[kAmaxRep] |dY|max (mode 1; atomicMax on the bit patterns), or nullptr
+  float* dT; int64_t ldt;    // mode 1: dY^T [dim][ldt] as well (rows..ldt zero-filled): the weight-gradient GEMM's operand
 };
 
 void launch_bwd_node_upd(const BwdRoundParams& p, int mode, hipStream_t s);

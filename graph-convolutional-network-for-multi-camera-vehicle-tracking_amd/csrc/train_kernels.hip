@@ -616,11 +616,14 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p) {
       } else {
         const float dy = gam * istd * (g - mg - zh * mgz);
         p.dA[row * p.dim + col] = dy;
+        if (p.dT) p.dT[(int64_t)col * p.ldt + row] = dy;
         dymax = fmaxf(dymax, fabsf(dy));
         s0 += dy;
       }
     }
   }
+  if (MODE == 1 && p.dT && blockIdx.y == gridDim.y - 1 && col < p.dim)      // the transposed copy's padding rows
+    for (int64_t row = p.rows + rg; row < p.ldt; row += 4) p.dT[(int64_t)col * p.ldt + row] = 0.f;
   red[rg * 64 + cl] = s0;
   red[256 + rg * 64 + cl] = s1;
   __syncthreads();
