@@ -390,7 +390,7 @@ def run_training_step(device):
     params = mtmc_mpn.default_params(num_enc_steps=3, num_class_steps=3)
     torch.manual_seed(0)
     model = mtmc_mpn.MOTMPNet(copy.deepcopy(params), None, ARCH).to(device).train()
-    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, fused=True)   # one kernel for all 34 tensors
     ei = d.edge_index.t().contiguous().to(device).t()
     data = types.SimpleNamespace(x=d.x.to(device), edge_index=ei, edge_attr=d.edge_attr.to(device))
     labels = d.edge_labels.long().to(device)

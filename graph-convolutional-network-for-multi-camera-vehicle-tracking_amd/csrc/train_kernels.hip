@@ -372,15 +372,18 @@ __global__ __launch_bounds__(256) void bwd_edge_upd_kernel(BwdRoundParams p) {
 // ------------------------------------------------------------------------------------------------
 // node projection backward: d[h0|h] and the node-column blocks of the two update weights
 // ------------------------------------------------------------------------------------------------
+constexpr int kBwdProjNodes = 16;   // nodes per workgroup: 430 nodes must still give a few dozen workgroups (32: 14 us per
+                                    // launch on 14 CUs); the weight-gradient atomics meet N/16 deep on a word
 __global__ __launch_bounds__(256) void bwd_node_proj_kernel(BwdProjParams p) {
-  __shared__ float hs[32 * 65];
-  __shared__ float gs[32 * 41];
+  constexpr int NB = kBwdProjNodes;
+  __shared__ float hs[NB * 65];
+  __shared__ float gs[NB * 41];
   const int hn = p.hn, ldh = hn + 1;
-  const int64_t n_groups = (p.n_nodes + 31) / 32;
+  const int64_t n_groups = (p.n_nodes + NB - 1) / NB;
   for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
-    const int64_t node0 = g * 32;
+    const int64_t node0 = g * NB;
     __syncthreads();
-    for (int i = threadIdx.x; i < 32 * kH; i += blockDim.x) {
+    for (int i = threadIdx.x; i < NB * kH; i += blockDim.x) {
       const int n = i >> 5, kk = i & 31;
       const int64_t node = node0 + n;
       float v = 0.f, v0 = 0.f;
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(256) void bwd_node_proj_kernel(BwdProjParams p) {
       hs[n * ldh + (hn - kH) + kk] = v;
       if (hn == 2 * kH) hs[n * ldh + kk] = v0;
     }
-    for (int i = threadIdx.x; i < 32 * 40; i += blockDim.x) {
+    for (int i = threadIdx.x; i < NB * 40; i += blockDim.x) {
       const int n = i / 40, j = i % 40;
       const int64_t node = node0 + n;
       float v = 0.f;
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(256) void bwd_node_proj_kernel(BwdProjParams p) {
     }
     __syncthreads();
     // d[h0|h][node][c] = sum_j g[node][j] * W_j[c]
-    for (int i = threadIdx.x; i < 32 * hn; i += blockDim.x) {
+    for (int i = threadIdx.x; i < NB * hn; i += blockDim.x) {
       const int n = i / hn, c = i % hn;
       const int64_t node = node0 + n;
       if (node >= p.n_nodes) continue;
@@ -429,11 +432,11 @@ __global__ __launch_bounds__(256) void bwd_node_proj_kernel(BwdProjParams p) {
         p.g_h_prev[node * kH + cc] = s;
       }
     }
-    // weight gradients: 40 x hn outputs, each summed over this block's 32 nodes
+    // weight gradients: 40 x hn outputs, each summed over this block's NB nodes
     for (int i = threadIdx.x; i < 40 * hn; i += blockDim.x) {
       const int j = i / hn, c = i % hn;
       float s = 0.f;
-      for (int n = 0; n < 32; ++n) s = fmaf(gs[n * 41 + j], hs[n * ldh + c], s);
+      for (int n = 0; n < NB; ++n) s = fmaf(gs[n * 41 + j], hs[n * ldh + c], s);
       float* dst = j < 4 ? p.gr_ue_w + j * p.ue_ld + c
                          : (j < 8 ? p.gr_ue_w + (j - 4) * p.ue_ld + hn + c : p.gr_un_w + (j - 8) * p.un_ld + c);
       unsafeAtomicAdd(dst, s);
@@ -712,7 +715,7 @@ void launch_bwd_edge_upd(const BwdRoundParams& p, int mode, hipStream_t s) {
   else hipLaunchKernelGGL(bwd_edge_upd_kernel<1>, dim3(grid), dim3(256), 0, s, p);
 }
 void launch_bwd_node_proj(const BwdProjParams& p, hipStream_t s) {
-  hipLaunchKernelGGL(bwd_node_proj_kernel, dim3(cap((p.n_nodes + 31) / 32)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(bwd_node_proj_kernel, dim3(cap((p.n_nodes + kBwdProjNodes - 1) / kBwdProjNodes)), dim3(256), 0, s, p);
 }
 // L == 0 (reference models/mpn.py:295-297): the classifier sits directly on the encoded edges.
 // d e0 = Wc^T d logits; dWc = sum_e d logits (x) e0; dbc = sum_e d logits.
