@@ -90,6 +90,7 @@ void launch_split_rows(const float* X, int64_t ld, int64_t rows, int K, void* H,
 // SOURCE address: chunk `sp` of row r holds the row's 16-byte slot sp ^ g(r); the fragment reads apply the same XOR.
 //   BK = 64 (128-byte rows, two rows per 256-byte bank row):  g(r) = (r >> 1) & 7
 //   BK = 32 ( 64-byte rows, four rows per bank row):          g(r) = (r >> 2) & 3
+//   BK = 16 ( 32-byte rows, eight rows per bank row):         g(r) = (r >> 3) & 1
 // With these every 16-lane group of a ds_read_b128 (MI355X_MICROARCH.md, LDS) touches 16 distinct slots.
 // MODE 1 / 3 are timing experiments (no LDS-DMA / no fragment reads; results are garbage): DESIGN.md 8.
 // ------------------------------------------------------------------------------------------------
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(BT * 2, MINB) void gemm_f16p_kernel(SplitGemmParams
 
   // ---- LDS-DMA sources: thread t fills chunk (t % SLOTS) of rows (t / SLOTS) + RPI * j of every image
   const int r0 = threadIdx.x / SLOTS, sp = threadIdx.x % SLOTS;
-  const int gsrc = BK == 64 ? ((r0 >> 1) & 7) : ((r0 >> 2) & 3);     // RPI is a multiple of 16: g(r0 + RPI*j) = g(r0)
+  const int gsrc = BK == 64 ? ((r0 >> 1) & 7) : (BK == 32 ? ((r0 >> 2) & 3) : ((r0 >> 3) & 1));   // RPI % 16 == 0: g(r0 + RPI*j) = g(r0)
   const int scol = (sp ^ gsrc) * 8;
   const _Float16* src[4][IPI];
 #pragma unroll
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(BT * 2, MINB) void gemm_f16p_kernel(SplitGemmParams
 
   // ---- fragment reads: lane l takes row (l & 31), 16-byte slot 2*ks + (l >> 5) of the wave's 32-row blocks
   const int fr = lane & 31, hi = lane >> 5;
-  const int gl = BK == 64 ? ((fr >> 1) & 7) : ((fr >> 2) & 3);
+  const int gl = BK == 64 ? ((fr >> 1) & 7) : (BK == 32 ? ((fr >> 2) & 3) : ((fr >> 3) & 1));
   const int a_row = (wm * TI * 32 + fr) * ROWB, b_row = (wn * 64 + fr) * ROWB;
   const int sx = (hi ^ gl) * 16;                                  // slot (2*ks + hi) ^ gl = (2*ks) ^ (hi ^ gl)
 
@@ -195,7 +196,22 @@ __global__ __launch_bounds__(BT * 2, MINB) void gemm_f16p_kernel(SplitGemmParams
     }
   };
 
-  if (NBUF == 1) {
+  if (NBUF >= 3) {
+    // NBUF - 1 k-tiles of LDS-DMA in flight ACROSS the barriers: a counted vmcnt retires only the tile about to be
+    // multiplied, and the barrier is the raw instruction (__syncthreads() would drain the queue: vmcnt(0))
+    constexpr int GL = 4 * IPI;                       // LDS-DMA instructions per thread per k-tile
+#pragma unroll
+    for (int st = 0; st < NBUF - 1; ++st)
+      if (st < nk) issue(st, st);
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + NBUF - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * GL) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last tiles: nothing younger is in flight
+      __builtin_amdgcn_s_barrier();                   // tile kt is in LDS for every wave; tile kt-1's stage is free
+      if (kt + NBUF - 1 < nk) issue(kt + NBUF - 1, (kt + NBUF - 1) % NBUF);
+      multiply(kt % NBUF);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this wave's fragment reads are done before it
+    }                                                 // arrives at the barrier that frees the stage
+  } else if (NBUF == 1) {
     for (int kt = 0; kt < nk; ++kt) {
       __syncthreads();                 // every wave is done reading the stage
       issue(kt, 0);
@@ -290,6 +306,9 @@ int launch_gemm_presplit(const SplitGemmParams& p, hipStream_t s, int variant) {
     case 3: launch_variant<128, 32, 2, 2>(p, s); break;
     case 4: launch_variant<256, 32, 1, 1>(p, s); break;
     case 5: launch_variant<256, 64, 1, 1>(p, s); break;
+    case 6: launch_variant<256, 16, 4, 1>(p, s); break;       // counted-vmcnt pipeline, three k-tiles in flight
+    case 7: launch_variant<256, 16, 3, 1>(p, s); break;
+    case 8: launch_variant<128, 32, 3, 1>(p, s); break;
     case 11: launch_variant<256, 32, 2, 1, 1>(p, s); break;   // timing experiments: no LDS-DMA
     case 13: launch_variant<256, 32, 2, 1, 3>(p, s); break;   // no fragment reads
     default: launch_variant<256, 32, 2, 1>(p, s); break;
