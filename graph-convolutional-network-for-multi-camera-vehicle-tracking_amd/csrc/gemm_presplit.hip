@@ -92,9 +92,8 @@ void launch_split_rows(const float* X, int64_t ld, int64_t rows, int K, void* H,
 //   BK = 32 ( 64-byte rows, four rows per bank row):          g(r) = (r >> 2) & 3
 //   BK = 16 ( 32-byte rows, eight rows per bank row):         g(r) = (r >> 3) & 1
 // With these every 16-lane group of a ds_read_b128 (MI355X_MICROARCH.md, LDS) touches 16 distinct slots.
-// MODE 1 / 3 are timing experiments (no LDS-DMA / no fragment reads; results are garbage): DESIGN.md 8.
 // ------------------------------------------------------------------------------------------------
-template <int BT, int BK, int NBUF, int MINB, int MODE = 0>
+template <int BT, int BK, int NBUF, int MINB>
 __global__ __launch_bounds__(BT * 2, MINB) void gemm_f16p_kernel(SplitGemmParams p, int tiles_m, int tiles_n) {
   constexpr int NT = BT * 2;                     // threads
   constexpr int WN = BT / 64;                    // waves across the tile's columns (2 rows of waves)
@@ -132,7 +131,6 @@ __global__ __launch_bounds__(BT * 2, MINB) void gemm_f16p_kernel(SplitGemmParams
     src[3][j] = src[2][j] + (int64_t)p.Nout * p.K;
   }
   auto issue = [&](int kt, int buf) {
-    if (MODE == 1) return;
     unsigned char* st = smem + buf * STAGE + wid * 1024;          // + lane * 16 by the hardware
 #pragma unroll
     for (int im = 0; im < 4; ++im)
@@ -163,28 +161,16 @@ __global__ __launch_bounds__(BT * 2, MINB) void gemm_f16p_kernel(SplitGemmParams
     for (int ks = 0; ks < BK / 16; ++ks) {
       const int so = sx ^ (ks * 32);
       f16x8 a[TI][2], b[2][2];
-      if (MODE == 3) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int q = 0; q < 2; ++q)
+          a[i][q] = *reinterpret_cast<const f16x8*>(st + q * IMG + a_row + i * 32 * ROWB + so);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int i = 0; i < TI; ++i) a[i][q][e] = (_Float16)(float)(lane + ks);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j][q][e] = (_Float16)(float)(lane - ks);
-          }
-      } else {
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-          for (int q = 0; q < 2; ++q)
-            a[i][q] = *reinterpret_cast<const f16x8*>(st + q * IMG + a_row + i * 32 * ROWB + so);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int q = 0; q < 2; ++q)
-            b[j][q] = *reinterpret_cast<const f16x8*>(st + (2 + q) * IMG + b_row + j * 32 * ROWB + so);
-      }
+        for (int q = 0; q < 2; ++q)
+          b[j][q] = *reinterpret_cast<const f16x8*>(st + (2 + q) * IMG + b_row + j * 32 * ROWB + so);
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -283,7 +269,7 @@ __global__ __launch_bounds__(BT * 2, MINB) void gemm_f16p_kernel(SplitGemmParams
   }
 }
 
-template <int BT, int BK, int NBUF, int MINB, int MODE = 0>
+template <int BT, int BK, int NBUF, int MINB>
 static void launch_variant(const SplitGemmParams& p, hipStream_t s) {
   const int tiles_m = (int)((p.M + BT - 1) / BT), tiles_n = (p.Nout + BT - 1) / BT;
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
@@ -291,11 +277,11 @@ static void launch_variant(const SplitGemmParams& p, hipStream_t s) {
   if (lds < (size_t)4 * BT * sizeof(double)) lds = (size_t)4 * BT * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16p_kernel<BT, BK, NBUF, MINB, MODE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16p_kernel<BT, BK, NBUF, MINB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_f16p_kernel<BT, BK, NBUF, MINB, MODE>), dim3(grid), dim3(BT * 2), lds, s, p, tiles_m, tiles_n);
+  hipLaunchKernelGGL((gemm_f16p_kernel<BT, BK, NBUF, MINB>), dim3(grid), dim3(BT * 2), lds, s, p, tiles_m, tiles_n);
 }
 
 int launch_gemm_presplit(const SplitGemmParams& p, hipStream_t s, int variant) {
@@ -309,8 +295,6 @@ int launch_gemm_presplit(const SplitGemmParams& p, hipStream_t s, int variant) {
     case 6: launch_variant<256, 16, 4, 1>(p, s); break;       // counted-vmcnt pipeline, three k-tiles in flight
     case 7: launch_variant<256, 16, 3, 1>(p, s); break;
     case 8: launch_variant<128, 32, 3, 1>(p, s); break;
-    case 11: launch_variant<256, 32, 2, 1, 1>(p, s); break;   // timing experiments: no LDS-DMA
-    case 13: launch_variant<256, 32, 2, 1, 3>(p, s); break;   // no fragment reads
     default: launch_variant<256, 32, 2, 1>(p, s); break;
   }
   return 0;

@@ -73,7 +73,7 @@ def timeit(M, K, N, iters=20):
     base = t(lambda: lib.mtmc_linear_raw(A.data_ptr(), K, W.data_ptr(), b.data_ptr(), Y.data_ptr(), M, K, N, scr.data_ptr(),
                                          st.data_ptr(), s))
     print(f"M={M} K={K} N={N}: in-loop split (|.|max pass + GEMM) {base:.1f} us", flush=True)
-    for variant in [0, 1, 6, 7, 8, 11, 13]:   # 11 / 13: timing experiments (no LDS-DMA / no fragment reads)
+    for variant in [0, 1, 2, 3, 4, 5, 6, 7, 8]:
         full = t(lambda: run(M, K, N, variant, A, W, b, Y, work, scr, st))
         gemm = t(lambda: run(M, K, N, -variant - 1, A, W, b, Y, work, scr, st))
         print(f"  variant {variant}: split + GEMM {full:.1f} us, GEMM alone {gemm:.1f} us = "
