@@ -130,6 +130,20 @@ __device__ __forceinline__ void stat_gather(const double* src, int n, int stride
   }
 }
 
+// two blocks in ONE round trip: dst[0..nA) from A, dst[nA..nA+nB) from B (different lanes take them; called back to
+// back, two stat_gather loops are two dependent-latency episodes in every workgroup's prologue)
+__device__ __forceinline__ void stat_gather2(const double* srcA, int nA, int strideA, const double* srcB, int nB,
+                                             int strideB, double* dst) {
+  for (int i = threadIdx.x; i < nA + nB; i += blockDim.x) {
+    const double* src = i < nA ? srcA + i : srcB + (i - nA);
+    const int stride = i < nA ? strideA : strideB;
+    double s = 0;
+#pragma unroll
+    for (int r = 0; r < kStatRep; ++r) s += src[r * stride];
+    dst[i] = s;
+  }
+}
+
 // Block-wide sum of NV per-thread doubles; result atomically added to this block's replica of dst.
 // smem: at least NV * (blockDim.x/64) doubles.  All threads must call.
 template <int NV>

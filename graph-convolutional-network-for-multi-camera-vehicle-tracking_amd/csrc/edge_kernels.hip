@@ -390,8 +390,7 @@ __global__ __launch_bounds__(kTileC) void pass_c_kernel(RoundParams p) {
   };
   if (tile < n_tiles) fetch(tile);
   // BatchNorm affine of channel k of z2 from the moment statistics (node_stat_kernel + pass B)
-  stat_gather(p.stats + kRoundMOff + 4, 10, kMStride, st);
-  stat_gather(p.stats + kRoundZ2Off, 64, kZ2Stride, st + 10);
+  stat_gather2(p.stats + kRoundMOff + 4, 10, kMStride, p.stats + kRoundZ2Off, 64, kZ2Stride, st);
   __syncthreads();
   float sk, tk;
   {

@@ -77,8 +77,7 @@ __global__ __launch_bounds__(256) void bwd_node_upd_kernel(BwdRoundParams p) {
   __shared__ float dzt[MODE == 1 ? 8 * 32 * 33 : 1];
   __shared__ float4 a_all[32];
   const int k = threadIdx.x & 31, hw = threadIdx.x >> 5;
-  stat_gather(p.f.stats + kRoundMOff + 4, 10, kMStride, st);
-  stat_gather(p.f.stats + kRoundZ2Off, 64, kZ2Stride, st + 10);
+  stat_gather2(p.f.stats + kRoundMOff + 4, 10, kMStride, p.f.stats + kRoundZ2Off, 64, kZ2Stride, st);
   if (MODE == 1) stat_gather(p.bst, 64, kBwdStrideD, st + 74);
   __syncthreads();
   const float* aw = p.f.un_w + k * p.f.un_ld + p.f.un_eoff;
