@@ -11,7 +11,7 @@
 
 namespace mtmc {
 
-constexpr int kProjNodes = 32;   // nodes per block iteration
+constexpr int kProjNodes = 16;   // nodes per block iteration (16 lanes per node: 8 output groups x 2 halves of the k range)
 constexpr int kProjOut = 40;     // 4 (Pr) + 4 (Pc) + 32 (Q)
 
 __global__ __launch_bounds__(256) void node_proj_kernel(NodeProjParams p) {
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void node_proj_kernel(NodeProjParams p) {
   if (p.y_last && threadIdx.x < kH)
     bn_affine(p.y_stats[threadIdx.x], p.y_stats[kH + threadIdx.x], p.y_count, p.y_gamma[threadIdx.x],
               p.y_beta[threadIdx.x], ys[threadIdx.x], yt[threadIdx.x]);
-  const int nl = threadIdx.x >> 3, part = threadIdx.x & 7;
+  const int nl = threadIdx.x >> 4, part = (threadIdx.x >> 1) & 7, kh = threadIdx.x & 1;
   const int64_t n_groups = (p.n_nodes + kProjNodes - 1) / kProjNodes;
   for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
     const int64_t node0 = g * kProjNodes;
@@ -55,20 +55,23 @@ __global__ __launch_bounds__(256) void node_proj_kernel(NodeProjParams p) {
       hs[n * ldh + (hn - kH) + kk] = v;
       if (hn == 2 * kH) hs[n * ldh + kk] = (p.y_last || node >= p.n_nodes) ? v : p.h0[node * kH + kk];
     }
-    if (p.zero_buf) {                              // 32 nodes x 32 floats = 256 float4
+    if (p.zero_buf && threadIdx.x < kProjNodes * 8) {   // 16 nodes x 32 floats = 128 float4
       const int64_t node = node0 + (threadIdx.x >> 3);
       if (node < p.n_nodes)
         reinterpret_cast<float4*>(p.zero_buf + node * kH)[threadIdx.x & 7] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int kk = 0; kk < hn; ++kk) {
+    const int kq = hn >> 1;
+    for (int kk = kh * kq; kk < (kh + 1) * kq; ++kk) {
       const float hv = hs[nl * ldh + kk];
 #pragma unroll
       for (int i = 0; i < 5; ++i) acc[i] = fmaf(hv, wt[kk * kProjOut + part + 8 * i], acc[i]);
     }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) acc[i] += __shfl_xor(acc[i], 1, 64);
     const int64_t node = node0 + nl;
-    if (node < p.n_nodes) {
+    if (kh == 0 && node < p.n_nodes) {
       p.P[(part < 4 ? node : p.n_nodes + node) * 4 + (part & 3)] = acc[0];      // [Pr | Pc], see edge_z1
 #pragma unroll
       for (int i = 1; i < 5; ++i) p.Q[node * kH + part + 8 * (i - 1)] = acc[i];
