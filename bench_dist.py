@@ -50,7 +50,7 @@ def main_distributed(args):
     del full
     torch.cuda.empty_cache()
 
-    rr = mdist.row_ranges_of(ei_loc)          # row-sorted + snapped: complete rows per rank -> all-gather, not all-reduce
+    rr = mdist.row_ranges_of(ei_loc)          # row-sorted + snapped: complete rows per rank -> only Pc [N,4] travels per round
 
     def step():
         return mdist.sharded_forward(model, x_loc, (lo, hi, n), ei_loc, ea_loc, e, row_ranges=rr)
@@ -138,7 +138,7 @@ def main_distributed(args):
                 "dtype": "f32", "data": "synthetic (seeded graph and features; random-init weights)",
                 "config": {"workload": f"{name}: {desc}, L={L}, Cs={cs}, eval forward", "N": n, "E": e,
                            "parallelism": f"edge-range x{world} (rows of x range-partitioned for the encoder), "
-                                          "RCCL all-reduce of BatchNorm statistics; the [N,32] node state per round by " + ("all-gather of complete rows" if rr is not None else "all-reduce")},
+                                          "RCCL all-reduce of BatchNorm statistics; " + ("row-complete shards: each rank keeps its rows' node state, per round only the column projections Pc [N,4] are all-gathered, the [N,32] node state once at the end" if rr is not None else "the [N,32] node state all-reduced per round")},
                 "roofline": {"bound": "hbm", "achieved": b_fwd / sec / 1e9, "peak": bench.HBM_PEAK_GBS * world, "unit": "GB/s",
                              "frac": b_fwd / sec / 1e9 / (bench.HBM_PEAK_GBS * world), "traffic": None,
                              "kernel": "whole forward (SURVEY 8(d) algorithmic bytes over the step time, all ranks)"},

@@ -39,14 +39,15 @@ class Call(C.Structure):
                 ("n_edges_total", C.c_int64), ("node_lo", C.c_int64), ("node_hi", C.c_int64),
                 ("logits", C.c_void_p), ("h_out", C.c_void_p), ("workspace", C.c_void_p),
                 ("workspace_bytes", C.c_size_t), ("training", C.c_int32), ("flags", C.c_int32),
-                ("seed", C.c_uint64), ("stream", C.c_void_p)]
+                ("seed", C.c_uint64), ("stream", C.c_void_p), ("row_lo", C.c_int64), ("row_hi", C.c_int64)]
 
 
 class WsLayout(C.Structure):
     _fields_ = [("total_bytes", C.c_size_t), ("zero_bytes", C.c_size_t), ("flags_off", C.c_size_t),
                 ("stat_attr_off", C.c_size_t), ("stat_enc2_off", C.c_size_t), ("stat_enc_node_off", C.c_size_t),
                 ("stat_round_off", C.c_size_t), ("deg_off", C.c_size_t), ("seg_off", C.c_size_t),
-                ("h0_off", C.c_size_t), ("h_acc_off", C.c_size_t * 2), ("deg_global_off", C.c_size_t)]
+                ("h0_off", C.c_size_t), ("h_acc_off", C.c_size_t * 2), ("deg_global_off", C.c_size_t),
+                ("P_off", C.c_size_t)]
 
 
 # statistics blocks (include/mtmc_mpn.h): replicas x stride doubles each
@@ -130,7 +131,7 @@ def load() -> C.CDLL:
     lib.mtmc_mlp_layer_forward.restype = C.c_int32
     lib.mtmc_mlp_layer_forward.argtypes = [C.POINTER(Layer), C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                            C.c_void_p]
-    if lib.mtmc_mpn_abi_version() != 2:
+    if lib.mtmc_mpn_abi_version() != 3:
         raise RuntimeError("mtmc_mpn: ABI version mismatch between _lib.py and libmtmc_mpn.so")
     _lib = lib
     return lib

@@ -102,6 +102,7 @@ inline void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* l
   lo->row_start = take((size_t)N * sizeof(int32_t));
   lo->carry = take((size_t)((E + 31) / 32) * 2 * 32 * sizeof(float));
   lo->P = take((size_t)N * 8 * sizeof(float));
+  lo->pub.P_off = lo->P;
   lo->Q = take((size_t)N * 32 * sizeof(float));
   lo->row32 = take((size_t)E * sizeof(int32_t));
   lo->col32 = take((size_t)E * sizeof(int32_t));
@@ -177,6 +178,9 @@ inline int make_ctx(const mtmc_mpn_model* m, const mtmc_mpn_call* c, Ctx* ctx) {
   if (c->n_edges < 0 || c->n_edges > c->n_edges_total || c->n_edges >= (1ll << 31) || c->n_nodes >= (1ll << 31))
     return fail(MTMC_E_ARG, "edge/node counts out of range");
   if (c->node_lo < 0 || c->node_hi < c->node_lo || c->node_hi > c->n_nodes) return fail(MTMC_E_ARG, "bad node range");
+  if (c->row_lo < 0 || c->row_hi < c->row_lo || c->row_hi > c->n_nodes) return fail(MTMC_E_ARG, "bad row range");
+  if (c->training && (c->row_lo != 0 || (c->row_hi != 0 && c->row_hi != c->n_nodes)))
+    return fail(MTMC_E_ARG, "training calls project every node row (row_lo = row_hi = 0)");
   if (!c->x || !c->edge_attr || !c->logits || !c->h_out || !c->workspace) return fail(MTMC_E_ARG, "NULL tensor pointer");
   if (c->n_edges > 0 && (!c->row || !c->col)) return fail(MTMC_E_ARG, "NULL edge_index pointer");
   if (c->idx_stride < 1) return fail(MTMC_E_ARG, "idx_stride must be >= 1");
@@ -225,6 +229,9 @@ inline float* agg_target(const Ctx& x, int r) {
   return x.at<float>(x.lo.pub.h_acc_off[r & 1]);
 }
 // the (unscaled) node state round r reads: h0 for the first round, else what round r-1 aggregated
+// rows whose projections / node-update statistics this call computes (mtmc_mpn_call::row_lo / row_hi; 0,0 = all)
+inline int64_t proj_lo(const mtmc_mpn_call* c) { return c->row_hi > 0 ? c->row_lo : 0; }
+inline int64_t proj_hi(const mtmc_mpn_call* c) { return c->row_hi > 0 ? c->row_hi : c->n_nodes; }
 inline float* round_h_src(const Ctx& x, int r) {
   if (r == 0) return x.at<float>(x.lo.pub.h0_off);
   return x.lo.training ? x.at<float>(x.lo.h_tr[r - 1]) : x.at<float>(x.lo.pub.h_acc_off[(r - 1) & 1]);
@@ -370,6 +377,7 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
       p.P = round_P(x, arg); p.Q = round_Q(x, arg);
       p.zero_buf = agg_target(x, arg);
       p.n_nodes = c->n_nodes;
+      p.node_begin = proj_lo(c); p.node_end = proj_hi(c);
       mtmc::launch_node_proj(p, s);
       break;
     }
@@ -392,6 +400,7 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
       p.un_eoff = (m->reattach_nodes ? 2 : 1) * MTMC_NODE_DIM;
       p.stats = x.at<double>(x.lo.pub.stat_round_off) + (size_t)arg * mtmc::kRoundBlock;
       p.n_nodes = c->n_nodes;
+      p.node_begin = proj_lo(c); p.node_end = proj_hi(c);
       mtmc::launch_node_stat(p, s);
       break;
     }

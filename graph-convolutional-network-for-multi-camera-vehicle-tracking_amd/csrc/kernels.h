@@ -55,7 +55,8 @@ struct NodeProjParams {
   int hn;                    // 32 or 64: width of [h0 | h]
   float* P; float* Q;
   float* zero_buf;           // [N][32] cleared for the coming aggregation, or nullptr
-  int64_t n_nodes;
+  int64_t n_nodes;           // N (global): the Pc half of P starts at P + 4 N
+  int64_t node_begin, node_end;   // rows to project: [0, N), or the source rows of a row-complete edge shard
 };
 
 struct NodeStatParams {
@@ -63,6 +64,7 @@ struct NodeStatParams {
   const float* un_w; const float* un_b; int un_ld; int un_eoff;
   double* stats;             // this round's block; z2 sums at kRoundZ2
   int64_t n_nodes;
+  int64_t node_begin, node_end;   // as in NodeProjParams
 };
 
 struct GemmParams {

@@ -33,16 +33,16 @@ __global__ __launch_bounds__(256) void node_proj_kernel(NodeProjParams p) {
     bn_affine(p.y_stats[threadIdx.x], p.y_stats[kH + threadIdx.x], p.y_count, p.y_gamma[threadIdx.x],
               p.y_beta[threadIdx.x], ys[threadIdx.x], yt[threadIdx.x]);
   const int nl = threadIdx.x >> 4, part = (threadIdx.x >> 1) & 7, kh = threadIdx.x & 1;
-  const int64_t n_groups = (p.n_nodes + kProjNodes - 1) / kProjNodes;
+  const int64_t n_groups = (p.node_end - p.node_begin + kProjNodes - 1) / kProjNodes;
   for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
-    const int64_t node0 = g * kProjNodes;
+    const int64_t node0 = p.node_begin + g * kProjNodes;
     __syncthreads();                               // wt/ys ready / previous hs consumed
     // stage the h rows of 32 nodes (1024 floats), then mirror / fetch the h0 half when reattaching
     for (int i = threadIdx.x; i < kProjNodes * kH; i += blockDim.x) {
       const int n = i >> 5, kk = i & 31;
       const int64_t node = node0 + n;
       float v = 0.f;
-      if (node < p.n_nodes) {
+      if (node < p.node_end) {
         if (p.y_last) {
           v = drop_apply(p.drop, p.drop_stream, (unsigned long long)node * kH + kk,
                          fmaxf(fmaf(p.y_last[node * kH + kk], ys[kk], yt[kk]), 0.f));
@@ -53,11 +53,11 @@ __global__ __launch_bounds__(256) void node_proj_kernel(NodeProjParams p) {
         }
       }
       hs[n * ldh + (hn - kH) + kk] = v;
-      if (hn == 2 * kH) hs[n * ldh + kk] = (p.y_last || node >= p.n_nodes) ? v : p.h0[node * kH + kk];
+      if (hn == 2 * kH) hs[n * ldh + kk] = (p.y_last || node >= p.node_end) ? v : p.h0[node * kH + kk];
     }
     if (p.zero_buf && threadIdx.x < kProjNodes * 8) {   // 16 nodes x 32 floats = 128 float4
       const int64_t node = node0 + (threadIdx.x >> 3);
-      if (node < p.n_nodes)
+      if (node < p.node_end)
         reinterpret_cast<float4*>(p.zero_buf + node * kH)[threadIdx.x & 7] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void node_proj_kernel(NodeProjParams p) {
 #pragma unroll
     for (int i = 0; i < 5; ++i) acc[i] += __shfl_xor(acc[i], 1, 64);
     const int64_t node = node0 + nl;
-    if (kh == 0 && node < p.n_nodes) {
+    if (kh == 0 && node < p.node_end) {
       p.P[(part < 4 ? node : p.n_nodes + node) * 4 + (part & 3)] = acc[0];      // [Pr | Pc], see edge_z1
 #pragma unroll
       for (int i = 1; i < 5; ++i) p.Q[node * kH + part + 8 * (i - 1)] = acc[i];
@@ -91,10 +91,10 @@ __global__ __launch_bounds__(256) void node_stat_kernel(NodeStatParams p) {
   for (int j = 0; j < 4; ++j) a[j] = p.un_w[k * p.un_ld + p.un_eoff + j];
   const float b = p.un_b[k];
   double s1 = 0, s2 = 0;
-  const int64_t n_groups = (p.n_nodes + 7) / 8;
+  const int64_t n_groups = (p.node_end - p.node_begin + 7) / 8;
   for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
-    const int64_t node = g * 8 + slot;
-    if (node < p.n_nodes) {
+    const int64_t node = p.node_begin + g * 8 + slot;
+    if (node < p.node_end) {
       const double d = (double)p.deg[node];
       const double qb = (double)(p.Q[node * kH + k] + b);
       double proj = 0;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void node_stat_kernel(NodeStatParams p) {
       s2 += d * qb * qb + 2.0 * qb * proj;
     }
     __syncthreads();                               // every channel has read seg[node]
-    if (node < p.n_nodes && k < 4) p.seg[node * 4 + k] = 0.0;   // ready for the next round
+    if (node < p.node_end && k < 4) p.seg[node * 4 + k] = 0.0;   // ready for the next round
   }
   red[slot * 32 + k] = s1;
   red[256 + slot * 32 + k] = s2;
@@ -162,10 +162,10 @@ __global__ __launch_bounds__(256) void h_final_kernel(const float* src, const in
 static inline int cap_grid(int64_t blocks) { return (int)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks)); }
 
 void launch_node_proj(const NodeProjParams& p, hipStream_t s) {
-  hipLaunchKernelGGL(node_proj_kernel, dim3(cap_grid((p.n_nodes + kProjNodes - 1) / kProjNodes)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(node_proj_kernel, dim3(cap_grid((p.node_end - p.node_begin + kProjNodes - 1) / kProjNodes)), dim3(256), 0, s, p);
 }
 void launch_node_stat(const NodeStatParams& p, hipStream_t s) {
-  hipLaunchKernelGGL(node_stat_kernel, dim3(cap_grid((p.n_nodes + 7) / 8)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(node_stat_kernel, dim3(cap_grid((p.node_end - p.node_begin + 7) / 8)), dim3(256), 0, s, p);
 }
 void launch_bn_relu_rows(const float* Y, int64_t ldy, int64_t rows, int dim, const double* stats, const float* gamma,
                          const float* beta, double count, float* dst, Drop drop, unsigned drop_stream, int64_t row0,

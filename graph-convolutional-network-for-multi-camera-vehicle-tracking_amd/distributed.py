@@ -13,6 +13,10 @@ hundred bytes to a few KB each), plus the two real data exchanges:
     after NODE_H0    all-gather of the encoded node rows h0                       [N,32] f32
     per round        z1 statistics | e' moments | z2 statistics (three small all-reduces)
                      all-reduce (sum or max) of the aggregated node state h'      [N,32] f32
+                     -- or, when every rank's edges have their source rows to themselves (row-sorted list, shards
+                     snapped to row boundaries): no exchange of h' at all; each rank projects its own rows and the
+                     ranks all-gather the column projections Pc                   [N,4]  f32   (8x fewer bytes),
+                     and the final node state once at the end                     [N,32] f32
 The per-node segment sums and degrees need no exchange: the z2 statistics are linear in them, so every rank
 evaluates its share and only the 64 sums travel.
 
@@ -59,6 +63,21 @@ def edge_ranges(row: Optional[torch.Tensor], n_edges: int, parts: int, snap_to_r
     return [(cuts[i], cuts[i + 1]) for i in range(parts)]
 
 
+def tile_rows(row_ranges, n_nodes):
+    """Row-disjoint source-row ranges (row_ranges_of) stretched to a partition of [0, N): rows without out-edges between
+    two ranges go to the earlier one, so that every node row is projected, cleared and reported by exactly one rank."""
+    world = len(row_ranges)
+    order = sorted((r for r in range(world) if row_ranges[r][1] > row_ranges[r][0]), key=lambda r: row_ranges[r][0])
+    tiled = [(0, 0)] * world
+    for i, r in enumerate(order):
+        lo = 0 if i == 0 else row_ranges[r][0]
+        hi = n_nodes if i == len(order) - 1 else row_ranges[order[i + 1]][0]
+        tiled[r] = (lo, hi)
+    if not order:
+        tiled[0] = (0, n_nodes)
+    return tiled
+
+
 class ShardedForward:
     """Runs one forward on this rank's shard.  `backend` is a ForwardEngine (HIP) or anything with the same
     five methods."""
@@ -98,13 +117,19 @@ class ShardedForward:
         """x_local: rows [node_range[0], node_range[1]) of x; node_range = (lo, hi, N).
         edge_index_local / edge_attr_local: this rank's edge slice (global node ids).
         row_ranges: per rank, the node range [lo, hi) that contains ALL source rows of its edge slice and no source
-        row of any other rank's (see `row_ranges_of`); when given, the node states are exchanged by all-gather
-        instead of all-reduce."""
+        row of any other rank's (see `row_ranges_of`).  When given, a rank aggregates complete rows, so it keeps the node
+        state of its own rows to itself: it projects only those rows (Pr, Q are only ever read at an edge's source row)
+        and the ranks exchange the column projections Pc -- 16 bytes per node and round instead of the 128 bytes of the
+        node state -- plus the final node state once, for the replicated output.  Without it the aggregated state is
+        all-reduced every round and every rank projects every node."""
         be, spec = self.backend, self.spec
         world = dist.get_world_size(self.group)
         rank = dist.get_rank(self.group)
+        local_rows = row_ranges is not None
+        if local_rows:
+            row_ranges = tile_rows(row_ranges, node_range[2])
         prep = be.prepare(x_local, edge_index_local, edge_attr_local, n_edges_total=n_edges_total,
-                          node_range=node_range)
+                          node_range=node_range, **({"row_range": row_ranges[rank]} if local_rows else {}))
         n = node_range[2]
         mean = spec.agg == "mean"
         if mean:
@@ -135,6 +160,9 @@ class ShardedForward:
                         if hi > lo:
                             dist.broadcast(h0[lo:hi], src=dist.get_global_rank(self.group, r) if self.group else r,
                                            group=self.group)
+            elif ph == _lib.PH_ROUND_PROJ:
+                if local_rows:                     # every rank gathers along its edges' columns: all of Pc
+                    self._gather_rows(be.region(prep, "Pc"), row_ranges, rank, world)
             elif ph == _lib.PH_ROUND_A:
                 self._sum(be.region(prep, "round_z1", arg))
             elif ph == _lib.PH_ROUND_B:
@@ -142,12 +170,12 @@ class ShardedForward:
             elif ph == _lib.PH_ROUND_STAT:
                 self._sum(be.region(prep, "round_z2", arg))
             elif ph == _lib.PH_ROUND_C:
-                h = be.region(prep, "agg", arg)
-                if row_ranges is not None:
-                    self._gather_rows(h, row_ranges, rank, world)
-                else:
-                    (self._max if spec.agg == "max" else self._sum)(h)
-        return be.outputs(prep)
+                if not local_rows:
+                    (self._max if spec.agg == "max" else self._sum)(be.region(prep, "agg", arg))
+        logits, h = be.outputs(prep)
+        if local_rows and spec.num_enc_steps > 0:  # the replicated output: every rank's rows of the final node state
+            self._gather_rows(h, row_ranges, rank, world)
+        return logits, h
 
 
 def row_ranges_of(edge_index_local, group=None):

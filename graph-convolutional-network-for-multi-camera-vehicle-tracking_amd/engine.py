@@ -118,9 +118,11 @@ class ForwardEngine:
             raise RuntimeError("mtmc_mpn: edge_index must be int64")
 
     def prepare(self, x, edge_index, edge_attr, training=False, n_edges_total=None, node_range=None, tape=False,
-                seed=0):
+                seed=0, row_range=None):
         """Validate, allocate outputs/workspace and fill the two C structs of one call.
-        `tape=True`: training-mode layout in a fresh workspace that the backward will read (kept by autograd)."""
+        `tape=True`: training-mode layout in a fresh workspace that the backward will read (kept by autograd).
+        `row_range=(lo, hi)`: multi-GPU, row-complete edge shard -- project / take node statistics of these rows only
+        (mtmc_mpn_call::row_lo / row_hi)."""
         self.check_inputs(x, edge_index, edge_attr)
         s, dev = self.spec, x.device
         e = edge_index.shape[1]
@@ -155,6 +157,9 @@ class ForwardEngine:
         call.n_nodes, call.n_edges = n, e
         call.n_edges_total = e if n_edges_total is None else n_edges_total
         call.node_lo, call.node_hi = node_lo, node_hi
+        if row_range is not None:                      # (k, k) with k > 0 is the empty range; (0, 0) means "all"
+            rlo, rhi = int(row_range[0]), int(row_range[1])
+            call.row_lo, call.row_hi = (rlo, rhi) if rhi > rlo else (max(rlo, 1), max(rlo, 1))
         call.logits = logits.data_ptr() if logits.numel() else ws.data_ptr()
         call.h_out = h.data_ptr()
         call.workspace, call.workspace_bytes = ws.data_ptr(), ws.numel()
@@ -216,6 +221,9 @@ class ForwardEngine:
             return ws[lay.deg_global_off:lay.deg_global_off + 4 * n].view(torch.int32)
         if name == "h0":
             return ws[lay.h0_off:lay.h0_off + 128 * n].view(torch.float32).view(n, 32)
+        if name == "Pc":                       # the round's column projections [N][4] (second half of P)
+            off = lay.P_off + 16 * n
+            return ws[off:off + 16 * n].view(torch.float32).view(n, 4)
         if name == "agg":                      # where round idx aggregates (see mtmc_ws_layout.h_acc_off)
             if idx == s.num_enc_steps - 1 and s.agg != "mean":
                 return prep.h

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MTMC_MPN_ABI_VERSION 2
+#define MTMC_MPN_ABI_VERSION 3
 
 #define MTMC_MAX_ENC_LAYERS 8   /* hidden layers of the node encoder MLP          */
 #define MTMC_NODE_DIM 32        /* H : width of the node state the kernels are built for */
@@ -107,6 +107,9 @@ typedef struct mtmc_mpn_call {
   int32_t flags;             /* MTMC_F_*                                                */
   uint64_t seed;
   void* stream;              /* hipStream_t                                             */
+  int64_t row_lo, row_hi;    /* multi-GPU, row-complete edge shards: MTMC_PH_ROUND_PROJ / _STAT work on node rows
+                                [row_lo,row_hi) only -- the source rows of this call's edges; the host then exchanges
+                                the column projections (mtmc_ws_layout.P_off) instead of the node state.  0,0 = all */
 } mtmc_mpn_call;
 
 #define MTMC_F_DETERMINISTIC 1   /* row-sorted edge lists: sum/mean aggregation through per-chunk partials added in
@@ -140,6 +143,8 @@ typedef struct mtmc_ws_layout {
                                 except that the last round of a sum/max model aggregates into h_out       */
   size_t deg_global_off;     /* i32[N]  degree over all shards; read instead of deg for mean aggregation
                                 when MTMC_F_GLOBAL_DEG is set (the host fills it)                         */
+  size_t P_off;              /* f32[2][N][4] the round's edge-update projections: Pr rows, then Pc rows (gathered
+                                by column: every shard needs ALL of Pc, 16 B per node, and only its own Pr / Q)   */
 } mtmc_ws_layout;
 
 enum {                       /* phases in forward order; `arg` = encoder layer or round (0-based) */

@@ -63,7 +63,7 @@ class CpuPhaseBackend:
                     (_lib.PH_ROUND_C, r)]
         return seq + [(_lib.PH_END, 0)]
 
-    def prepare(self, x, edge_index, edge_attr, training=False, n_edges_total=None, node_range=None):
+    def prepare(self, x, edge_index, edge_attr, training=False, n_edges_total=None, node_range=None, row_range=None):
         s = self.spec
         lo, hi, n = node_range if node_range is not None else (0, x.shape[0], x.shape[0])
         e = edge_index.shape[1]
@@ -80,7 +80,8 @@ class CpuPhaseBackend:
             deg=torch.zeros(n, dtype=torch.int32), deg_global=torch.zeros(n, dtype=torch.int32),
             seg=torch.zeros(n, 4, dtype=F64), h0=torch.zeros(n, 32), h_acc=[torch.zeros(n, 32), torch.zeros(n, 32)],
             h=torch.zeros(n, 32), logits=torch.zeros(n_out, e, s.cls_edge[0].out_dim), n_out=n_out,
-            Y=[None] * len(s.enc_node), e_buf=None, P=None, Q=None, enc_aff=None)
+            Y=[None] * len(s.enc_node), e_buf=None, P=torch.full((n, 8), float("nan")), Q=None, enc_aff=None,
+            rows=(0, n) if row_range is None else (int(row_range[0]), int(row_range[1])))
         return c
 
     def set_flags(self, c, flags):
@@ -91,6 +92,8 @@ class CpuPhaseBackend:
             return getattr(c, name)
         if name in ("stat_enc_node", "round_z1", "round_m", "round_z2"):
             return getattr(c, name)[idx]
+        if name == "Pc":
+            return c.P[:, 4:]
         if name == "agg":
             return c.h if (idx == self.spec.num_enc_steps - 1 and self.spec.agg != "mean") else c.h_acc[idx & 1]
         raise KeyError(name)
@@ -189,9 +192,15 @@ class CpuPhaseBackend:
                     deg = c.deg_global if (c.flags & _lib.F_GLOBAL_DEG) else c.deg
                     h = h / deg.clamp(min=1).float()[:, None]
             hcat = torch.cat([c.h0, h], 1) if s.reattach_nodes else h
-            c.P = torch.cat([hcat @ w.w_pr.t(), hcat @ w.w_pc.t()], 1)
-            c.Q = hcat @ w.w_q.t()
-            self.region(c, "agg", arg).zero_()
+            lo, hi = c.rows                        # like the kernels: only these rows are projected and cleared; the
+            c.P.fill_(float("nan"))                # rest is poison until the host has exchanged it
+            c.P[lo:hi] = torch.cat([hcat[lo:hi] @ w.w_pr.t(), hcat[lo:hi] @ w.w_pc.t()], 1)
+            c.Q = torch.full((c.n, 32), float("nan"))
+            c.Q[lo:hi] = hcat[lo:hi] @ w.w_q.t()
+            tgt = self.region(c, "agg", arg)
+            if (lo, hi) != (0, c.n):
+                tgt.fill_(float("nan"))
+            tgt[lo:hi] = 0
         elif ph == _lib.PH_ROUND_A:
             z1 = self._z1(c, arg).to(F64)
             c.round_z1[arg].zero_()
@@ -207,9 +216,10 @@ class CpuPhaseBackend:
             c.seg.index_add_(0, c.row, e_new.to(F64))
         elif ph == _lib.PH_ROUND_STAT:
             w = self._weights()
-            qb = (c.Q + w.bn).to(F64)
-            proj = c.seg @ w.w_a.to(F64).t()
-            deg = c.deg.to(F64)[:, None]
+            lo, hi = c.rows
+            qb = (c.Q[lo:hi] + w.bn).to(F64)
+            proj = c.seg[lo:hi] @ w.w_a.to(F64).t()
+            deg = c.deg[lo:hi].to(F64)[:, None]
             c.round_z2[arg].zero_()
             c.round_z2[arg][:64] = torch.cat([(deg * qb + proj).sum(0), (deg * qb * qb + 2 * qb * proj).sum(0)])
             c.seg.zero_()

@@ -100,6 +100,72 @@ def test_row_complete_shards_use_all_gather(name, world, snap, tmp_path):
     _run(name, world, snap, tmp_path, gather=True)
 
 
+def test_tile_rows():
+    assert mdist.tile_rows([(2, 5), (7, 9)], 12) == [(0, 7), (7, 12)]          # gaps go to the earlier rank
+    assert mdist.tile_rows([(6, 9), (0, 0), (1, 4)], 10) == [(6, 10), (0, 0), (0, 6)]   # rank order is free; empty shard
+    assert mdist.tile_rows([(0, 0), (0, 0)], 5) == [(0, 5), (0, 0)]            # no edges at all
+
+
+def _gap_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from cpu_phase_backend import CpuPhaseBackend
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m, d = _gap_case()
+        sd = {k: v.detach() for k, v in m.state_dict().items()}
+        n, e = d.x.shape[0], d.edge_index.shape[1]
+        lo, hi = mdist.even_ranges(n, world)[rank]
+        elo, ehi = mdist.edge_ranges(d.edge_index[0], e, world, snap_to_rows=True)[rank]
+        rr = mdist.row_ranges_of(d.edge_index[:, elo:ehi])
+        assert rr is not None
+        with torch.no_grad():
+            logits, h = mdist.ShardedForward(CpuPhaseBackend(sd, m.spec), m.spec)(
+                d.x[lo:hi], (lo, hi, n), d.edge_index[:, elo:ehi], d.edge_attr[elo:ehi], e, rr)
+        torch.save({"logits": [l.clone() for l in logits], "h": h.clone()}, os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def _gap_case():
+    """Row-sorted camera graph from which every out-edge of some nodes is removed (they stay as edge targets): rows
+    no rank's edges start from -- at the front, between two shards and at the end of the node range."""
+    import copy
+    import mtmc_mpn
+    from mtmc_mpn import graphs
+    d = graphs.camera_graph((9, 7, 8), seed=4)
+    n = d.x.shape[0]
+    dead = torch.tensor([0, 1, 11, 12, 13, n - 1])
+    keep = ~torch.isin(d.edge_index[0], dead)
+    d.edge_index, d.edge_attr = d.edge_index[:, keep].contiguous(), d.edge_attr[keep].contiguous()
+    torch.manual_seed(3)
+    p = mtmc_mpn.default_params(num_enc_steps=2, num_class_steps=2)
+    p["node_agg_fn"] = "mean"
+    return mtmc_mpn.MOTMPNet(copy.deepcopy(p), None, "resnet101").eval(), d
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rows_without_out_edges_in_row_complete_shards(world, tmp_path):
+    from cpu_phase_backend import CpuPhaseBackend
+    mp.spawn(_gap_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    m, d = _gap_case()
+    be = CpuPhaseBackend({k: v.detach() for k, v in m.state_dict().items()}, m.spec)
+    with torch.no_grad():
+        ctx = be.prepare(d.x, d.edge_index, d.edge_attr)
+        for ph, arg in be.phase_list():
+            be.run_phase(ctx, ph, arg)
+        want_logits, want_h = be.outputs(ctx)
+    parts = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt")) for r in range(world)]
+    for i, w in enumerate(want_logits):
+        got = torch.cat([q["logits"][i] for q in parts], 0)
+        assert got.shape == w.shape and (got - w).abs().max().item() <= 1e-5
+    for q in parts:
+        assert torch.isfinite(q["h"]).all() and (q["h"] - want_h).abs().max().item() <= 1e-5
+    assert (want_h[0] == 0).all()                   # a node nothing flows out of aggregates nothing
+
+
 def test_ranges():
     assert mdist.even_ranges(10, 3) == [(0, 4), (4, 7), (7, 10)]
     row = torch.tensor([0, 0, 0, 1, 1, 2, 2, 2, 2, 3])

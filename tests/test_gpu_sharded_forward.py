@@ -1,7 +1,8 @@
 """Edge-partitioned forward on the REAL kernels: 2 and 3 ranks share the test box's one GPU over gloo (on a multi-GPU
 node the same code runs over RCCL, one rank per GPU), every rank encodes its node rows and walks its edge slice, and
-the stitched logits / replicated node states must equal the one-process forward of the same graph.  Covers both ways
-of exchanging the node states (all-reduce; all-gather of complete rows for row-snapped slices), all aggregations."""
+the stitched logits / replicated node states must equal the one-process forward of the same graph.  Covers both
+exchange schemes (all-reduce of the node state; row-complete shards that keep their rows' state and all-gather the
+column projections), all aggregations, and node rows no edge starts from."""
 import copy
 import os
 import socket
@@ -18,8 +19,15 @@ def _case(agg):
     import mtmc_mpn
     from mtmc_mpn import graphs
     d = graphs.camera_graph((31, 24, 17, 29), seed=5)
+    if agg.endswith("+gaps"):      # nodes without out-edges (still edge targets): at the front, inside, at the end
+        agg = agg[:-5]
+        dead = torch.tensor([0, 1, 2, 40, 41, 57, d.x.shape[0] - 2, d.x.shape[0] - 1])
+        keep = ~torch.isin(d.edge_index[0], dead)
+        d.edge_index, d.edge_attr = d.edge_index[:, keep].contiguous(), d.edge_attr[keep].contiguous()
     p = mtmc_mpn.default_params(num_enc_steps=3, num_class_steps=2)
     p["node_agg_fn"] = agg
+    if agg == "max":
+        p["reattach_initial_nodes"] = True
     return d, p
 
 
@@ -52,7 +60,8 @@ def _worker(rank, world, port, agg, snap, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,agg,snap", [(2, "sum", False), (2, "mean", True), (3, "max", False), (3, "sum", True)])
+@pytest.mark.parametrize("world,agg,snap", [(2, "sum", False), (2, "mean", True), (3, "max", False), (3, "sum", True),
+                                            (3, "mean+gaps", True), (2, "max", True)])
 def test_sharded_forward_on_the_gpu_kernels(world, agg, snap, tmp_path):
     import types
     import mtmc_mpn
