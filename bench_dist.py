@@ -42,18 +42,18 @@ def main_distributed(args):
     # every rank generates the same seeded graph on its own GPU, then keeps only its shard
     full = bench.make_workload(name, device)
     n, e = full.x.shape[0], full.edge_index.shape[1]
-    lo, hi = mdist.even_ranges(n, world)[rank]
     elo, ehi = mdist.edge_ranges(full.edge_index[0], e, world, snap_to_rows=True)[rank]
-    x_loc = full.x[lo:hi].clone()
     ei_loc = full.edge_index[:, elo:ehi].clone()
     ea_loc = full.edge_attr[elo:ehi].clone()
+    rr = mdist.row_ranges_of(ei_loc)          # row-sorted + snapped: complete rows per rank -> only Pc [N,4] travels per round
+    own = rr is not None                      # ... and the rank encodes exactly the rows it projects: h0 stays home too
+    lo, hi = mdist.tile_rows(rr, n)[rank] if own else mdist.even_ranges(n, world)[rank]
+    x_loc = full.x[lo:hi].clone()
     del full
     torch.cuda.empty_cache()
 
-    rr = mdist.row_ranges_of(ei_loc)          # row-sorted + snapped: complete rows per rank -> only Pc [N,4] travels per round
-
     def step():
-        return mdist.sharded_forward(model, x_loc, (lo, hi, n), ei_loc, ea_loc, e, row_ranges=rr)
+        return mdist.sharded_forward(model, x_loc, (lo, hi, n), ei_loc, ea_loc, e, row_ranges=rr, own_rows=own)
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -94,7 +94,7 @@ def main_distributed(args):
         s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s_ev.record()
         for _ in range(reps):
-            timed(x_loc, (lo, hi, n), ei_loc, ea_loc, e, rr)
+            timed(x_loc, (lo, hi, n), ei_loc, ea_loc, e, rr, own)
         e_ev.record()
         torch.cuda.synchronize(device)
         coll = sum(a.elapsed_time(b) for a, b in prep_evs) / reps

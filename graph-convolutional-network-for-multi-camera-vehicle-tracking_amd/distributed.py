@@ -113,7 +113,8 @@ class ShardedForward:
             if r != rank and rhi > rlo:
                 h[rlo:rhi] = parts[r][:rhi - rlo].to(h.device)
 
-    def __call__(self, x_local, node_range, edge_index_local, edge_attr_local, n_edges_total, row_ranges=None):
+    def __call__(self, x_local, node_range, edge_index_local, edge_attr_local, n_edges_total, row_ranges=None,
+                 own_rows=False):
         """x_local: rows [node_range[0], node_range[1]) of x; node_range = (lo, hi, N).
         edge_index_local / edge_attr_local: this rank's edge slice (global node ids).
         row_ranges: per rank, the node range [lo, hi) that contains ALL source rows of its edge slice and no source
@@ -121,7 +122,9 @@ class ShardedForward:
         state of its own rows to itself: it projects only those rows (Pr, Q are only ever read at an edge's source row)
         and the ranks exchange the column projections Pc -- 16 bytes per node and round instead of the 128 bytes of the
         node state -- plus the final node state once, for the replicated output.  Without it the aggregated state is
-        all-reduced every round and every rank projects every node."""
+        all-reduced every round and every rank projects every node.
+        own_rows (needs row_ranges): the rank ENCODES the node rows it projects -- node_range[:2] is its entry of
+        `tile_rows(row_ranges, N)` instead of the even split -- so the encoded state h0 needs no exchange either."""
         be, spec = self.backend, self.spec
         world = dist.get_world_size(self.group)
         rank = dist.get_rank(self.group)
@@ -134,9 +137,12 @@ class ShardedForward:
         mean = spec.agg == "mean"
         if mean:
             be.set_flags(prep, _lib.F_GLOBAL_DEG)        # (replaces the flags: the sharded path sums with atomics)
-        rows = even_ranges(n, world)
+        if own_rows and not local_rows:
+            raise ValueError("own_rows needs row_ranges (row-complete edge shards)")
+        rows = row_ranges if own_rows else even_ranges(n, world)
         if tuple(rows[rank]) != tuple(node_range[:2]):
-            raise ValueError(f"rank {rank} must encode node rows {rows[rank]} (even_ranges), got {node_range[:2]}")
+            raise ValueError(f"rank {rank} must encode node rows {rows[rank]} "
+                             f"({'tile_rows(row_ranges, N)' if own_rows else 'even_ranges'}), got {node_range[:2]}")
 
         for ph, arg in be.phase_list():
             be.run_phase(prep, ph, arg)
@@ -150,7 +156,7 @@ class ShardedForward:
                 self._sum(be.region(prep, "stat_enc2"))
             elif ph == _lib.PH_NODE_COMBINE:           # the layer's column statistics are complete here
                 self._sum(be.region(prep, "stat_enc_node", arg))
-            elif ph == _lib.PH_NODE_H0:
+            elif ph == _lib.PH_NODE_H0 and not own_rows:
                 h0 = be.region(prep, "h0")
                 even = all(hi - lo == rows[0][1] - rows[0][0] for lo, hi in rows)
                 if even and dist.get_backend(self.group) == "nccl":
@@ -173,7 +179,7 @@ class ShardedForward:
                 if not local_rows:
                     (self._max if spec.agg == "max" else self._sum)(be.region(prep, "agg", arg))
         logits, h = be.outputs(prep)
-        if local_rows and spec.num_enc_steps > 0:  # the replicated output: every rank's rows of the final node state
+        if local_rows and (spec.num_enc_steps > 0 or own_rows):   # the replicated output: every rank's rows of the final state
             self._gather_rows(h, row_ranges, rank, world)
         return logits, h
 
@@ -200,12 +206,12 @@ def row_ranges_of(edge_index_local, group=None):
 
 
 def sharded_forward(module, x_local, node_range, edge_index_local, edge_attr_local, n_edges_total, group=None,
-                    row_ranges=None):
+                    row_ranges=None, own_rows=False):
     """Convenience wrapper: one edge-partitioned forward of a (HIP-backed) MOTMPNet on this rank's shard.
     Returns ({'classified_edges': [local logits]}, h) with h replicated on every rank."""
     from . import engine
     if module._engine is None:
         module._engine = engine.ForwardEngine(module)
     logits, h = ShardedForward(module._engine, module.spec, group)(x_local, node_range, edge_index_local,
-                                                                  edge_attr_local, n_edges_total, row_ranges)
+                                                                  edge_attr_local, n_edges_total, row_ranges, own_rows)
     return {"classified_edges": logits}, h

@@ -180,6 +180,7 @@ class CpuPhaseBackend:
             st = c.stat_enc_node[-1]
             sc, sh = bn_affine(st[:32], st[32:], float(c.n), self.p(f"encoder.node_mlp.fc_layers.{lay.bn_slot}.weight"),
                                self.p(f"encoder.node_mlp.fc_layers.{lay.bn_slot}.bias"))
+            c.h0.fill_(float("nan"))                # rows this rank does not encode: poison until exchanged
             c.h0[c.lo:c.hi] = torch.relu(c.Y[-1] * sc + sh)
         elif ph == _lib.PH_ROUND_PROJ:
             w = self._weights()

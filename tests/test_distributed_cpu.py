@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case_name, snap, out_dir, gather=False):
+def _worker(rank, world, port, case_name, snap, out_dir, gather=False, own=False):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from cpu_phase_backend import CpuPhaseBackend
@@ -38,16 +38,18 @@ def _worker(rank, world, port, case_name, snap, out_dir, gather=False):
         if gather:
             rr = mdist.row_ranges_of(d.edge_index[:, elo:ehi])
             assert (rr is not None) == snap, "row-disjoint shards expected exactly for snapped boundaries"
+        if own:                                          # encode the rows the rank projects: no h0 exchange
+            lo, hi = mdist.tile_rows(rr, n)[rank]
         with torch.no_grad():
-            logits, h = fwd(d.x[lo:hi], (lo, hi, n), d.edge_index[:, elo:ehi], d.edge_attr[elo:ehi], e, rr)
+            logits, h = fwd(d.x[lo:hi], (lo, hi, n), d.edge_index[:, elo:ehi], d.edge_attr[elo:ehi], e, rr, own)
         torch.save({"elo": elo, "ehi": ehi, "logits": [l.clone() for l in logits], "h": h.clone()},
                    os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
 
-def _run(case_name, world, snap, tmp_path, gather=False):
-    mp.spawn(_worker, args=(world, _free_port(), case_name, snap, str(tmp_path), gather), nprocs=world, join=True)
+def _run(case_name, world, snap, tmp_path, gather=False, own=False):
+    mp.spawn(_worker, args=(world, _free_port(), case_name, snap, str(tmp_path), gather, own), nprocs=world, join=True)
     c = Case(case_name)
     parts = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt")) for r in range(world)]
     assert parts[0]["elo"] == 0 and parts[-1]["ehi"] == c.meta["E"]
@@ -100,13 +102,19 @@ def test_row_complete_shards_use_all_gather(name, world, snap, tmp_path):
     _run(name, world, snap, tmp_path, gather=True)
 
 
+@pytest.mark.parametrize("name,world", [("g5_reattach_both_s02", 2), ("g4_s02_L3", 3)])
+def test_row_complete_shards_that_encode_their_own_rows(name, world, tmp_path):
+    """own_rows: the encoder's row partition is the edge shards' source-row partition; h0 is never exchanged."""
+    _run(name, world, True, tmp_path, gather=True, own=True)
+
+
 def test_tile_rows():
     assert mdist.tile_rows([(2, 5), (7, 9)], 12) == [(0, 7), (7, 12)]          # gaps go to the earlier rank
     assert mdist.tile_rows([(6, 9), (0, 0), (1, 4)], 10) == [(6, 10), (0, 0), (0, 6)]   # rank order is free; empty shard
     assert mdist.tile_rows([(0, 0), (0, 0)], 5) == [(0, 5), (0, 0)]            # no edges at all
 
 
-def _gap_worker(rank, world, port, out_dir):
+def _gap_worker(rank, world, port, out_dir, own, L):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from cpu_phase_backend import CpuPhaseBackend
@@ -114,22 +122,24 @@ def _gap_worker(rank, world, port, out_dir):
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        m, d = _gap_case()
+        m, d = _gap_case(L)
         sd = {k: v.detach() for k, v in m.state_dict().items()}
         n, e = d.x.shape[0], d.edge_index.shape[1]
         lo, hi = mdist.even_ranges(n, world)[rank]
         elo, ehi = mdist.edge_ranges(d.edge_index[0], e, world, snap_to_rows=True)[rank]
         rr = mdist.row_ranges_of(d.edge_index[:, elo:ehi])
         assert rr is not None
+        if own:
+            lo, hi = mdist.tile_rows(rr, n)[rank]
         with torch.no_grad():
             logits, h = mdist.ShardedForward(CpuPhaseBackend(sd, m.spec), m.spec)(
-                d.x[lo:hi], (lo, hi, n), d.edge_index[:, elo:ehi], d.edge_attr[elo:ehi], e, rr)
+                d.x[lo:hi], (lo, hi, n), d.edge_index[:, elo:ehi], d.edge_attr[elo:ehi], e, rr, own)
         torch.save({"logits": [l.clone() for l in logits], "h": h.clone()}, os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
 
-def _gap_case():
+def _gap_case(L=2):
     """Row-sorted camera graph from which every out-edge of some nodes is removed (they stay as edge targets): rows
     no rank's edges start from -- at the front, between two shards and at the end of the node range."""
     import copy
@@ -141,16 +151,16 @@ def _gap_case():
     keep = ~torch.isin(d.edge_index[0], dead)
     d.edge_index, d.edge_attr = d.edge_index[:, keep].contiguous(), d.edge_attr[keep].contiguous()
     torch.manual_seed(3)
-    p = mtmc_mpn.default_params(num_enc_steps=2, num_class_steps=2)
+    p = mtmc_mpn.default_params(num_enc_steps=L, num_class_steps=2)
     p["node_agg_fn"] = "mean"
     return mtmc_mpn.MOTMPNet(copy.deepcopy(p), None, "resnet101").eval(), d
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_rows_without_out_edges_in_row_complete_shards(world, tmp_path):
+@pytest.mark.parametrize("world,own,L", [(2, False, 2), (3, False, 2), (3, True, 2), (2, True, 0)])
+def test_rows_without_out_edges_in_row_complete_shards(world, own, L, tmp_path):
     from cpu_phase_backend import CpuPhaseBackend
-    mp.spawn(_gap_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    m, d = _gap_case()
+    mp.spawn(_gap_worker, args=(world, _free_port(), str(tmp_path), own, L), nprocs=world, join=True)
+    m, d = _gap_case(L)
     be = CpuPhaseBackend({k: v.detach() for k, v in m.state_dict().items()}, m.spec)
     with torch.no_grad():
         ctx = be.prepare(d.x, d.edge_index, d.edge_attr)
@@ -163,7 +173,8 @@ def test_rows_without_out_edges_in_row_complete_shards(world, tmp_path):
         assert got.shape == w.shape and (got - w).abs().max().item() <= 1e-5
     for q in parts:
         assert torch.isfinite(q["h"]).all() and (q["h"] - want_h).abs().max().item() <= 1e-5
-    assert (want_h[0] == 0).all()                   # a node nothing flows out of aggregates nothing
+    if L > 0:
+        assert (want_h[0] == 0).all()               # a node nothing flows out of aggregates nothing
 
 
 def test_ranges():

@@ -31,7 +31,7 @@ def _case(agg):
     return d, p
 
 
-def _worker(rank, world, port, agg, snap, out_dir):
+def _worker(rank, world, port, agg, snap, out_dir, own=False):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import mtmc_mpn
@@ -50,9 +50,11 @@ def _worker(rank, world, port, agg, snap, out_dir):
         rr = mdist.row_ranges_of(ei) if snap else None
         if snap:
             assert rr is not None
+        if own:
+            lo, hi = mdist.tile_rows(rr, n)[rank]
         with torch.no_grad():
             out, h = mdist.sharded_forward(model, d.x[lo:hi].contiguous().to(dev), (lo, hi, n), ei,
-                                           d.edge_attr[elo:ehi].contiguous().to(dev), e, row_ranges=rr)
+                                           d.edge_attr[elo:ehi].contiguous().to(dev), e, row_ranges=rr, own_rows=own)
         torch.cuda.synchronize()
         torch.save({"logits": [o.cpu() for o in out["classified_edges"]], "h": h.cpu(), "edges": (elo, ehi)},
                    os.path.join(out_dir, f"rank{rank}.pt"))
@@ -60,15 +62,16 @@ def _worker(rank, world, port, agg, snap, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,agg,snap", [(2, "sum", False), (2, "mean", True), (3, "max", False), (3, "sum", True),
-                                            (3, "mean+gaps", True), (2, "max", True)])
-def test_sharded_forward_on_the_gpu_kernels(world, agg, snap, tmp_path):
+@pytest.mark.parametrize("world,agg,snap,own", [(2, "sum", False, False), (2, "mean", True, False), (3, "max", False, False),
+                                                (3, "sum", True, False), (3, "mean+gaps", True, False),
+                                                (2, "max", True, True), (3, "sum+gaps", True, True)])
+def test_sharded_forward_on_the_gpu_kernels(world, agg, snap, own, tmp_path):
     import types
     import mtmc_mpn
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(world, port, agg, snap, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, agg, snap, str(tmp_path), own), nprocs=world, join=True)
     parts = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt")) for r in range(world)]
     dev = torch.device("cuda:0")
     d, p = _case(agg)
