@@ -11,7 +11,7 @@ hundred bytes to a few KB each), plus the two real data exchanges:
     after EDGE_ENC   hidden edge-encoder moments
     after NODE_COMBINE l  column statistics of encoder layer l
     after NODE_H0    all-gather of the encoded node rows h0                       [N,32] f32
-    per round        z1 statistics | e' moments | z2 statistics (three small all-reduces)
+    per round        z1 statistics, then e' moments + z2 statistics together (two small all-reduces)
                      all-reduce (sum or max) of the aggregated node state h'      [N,32] f32
                      -- or, when every rank's edges have their source rows to themselves (row-sorted list, shards
                      snapped to row boundaries): no exchange of h' at all; each rank projects its own rows and the
@@ -171,10 +171,9 @@ class ShardedForward:
                     self._gather_rows(be.region(prep, "Pc"), row_ranges, rank, world)
             elif ph == _lib.PH_ROUND_A:
                 self._sum(be.region(prep, "round_z1", arg))
-            elif ph == _lib.PH_ROUND_B:
-                self._sum(be.region(prep, "round_m", arg))
-            elif ph == _lib.PH_ROUND_STAT:
-                self._sum(be.region(prep, "round_z2", arg))
+            elif ph == _lib.PH_ROUND_STAT:           # ROUND_STAT reads only local sums (segment sums, degrees, Q), so the
+                for t in be.region(prep, "round_m_z2", arg):   # e' moments of ROUND_B travel with its z2 sums: one message
+                    self._sum(t)
             elif ph == _lib.PH_ROUND_C:
                 if not local_rows:
                     (self._max if spec.agg == "max" else self._sum)(be.region(prep, "agg", arg))

@@ -208,6 +208,9 @@ class ForwardEngine:
         if name == "stat_enc_node":
             off = lay.stat_enc_node_off + 8 * sum(2 * l.out_dim for l in s.enc_node[:idx])
             return f64(off, 2 * s.enc_node[idx].out_dim)
+        if name == "round_m_z2":               # adjacent in the round block: one contiguous message
+            base = lay.stat_round_off + 8 * idx * _lib.ROUND_BLOCK + 8 * R * _lib.Z1_STRIDE
+            return (f64(base, R * (_lib.M_STRIDE + _lib.Z2_STRIDE)),)
         if name in ("round_z1", "round_m", "round_z2"):
             base = lay.stat_round_off + 8 * idx * _lib.ROUND_BLOCK
             if name == "round_z1":

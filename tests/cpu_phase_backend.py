@@ -92,6 +92,8 @@ class CpuPhaseBackend:
             return getattr(c, name)
         if name in ("stat_enc_node", "round_z1", "round_m", "round_z2"):
             return getattr(c, name)[idx]
+        if name == "round_m_z2":
+            return (c.round_m[idx], c.round_z2[idx])
         if name == "Pc":
             return c.P[:, 4:]
         if name == "agg":
