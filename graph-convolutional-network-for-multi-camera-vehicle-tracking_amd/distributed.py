@@ -151,7 +151,8 @@ class ShardedForward:
                 if mean:
                     g = be.region(prep, "deg_global")
                     g.copy_(be.region(prep, "deg"))
-                    self._sum(g)
+                    if not local_rows:             # row-complete shards: a row's whole degree is already local
+                        self._sum(g)
             elif ph == _lib.PH_EDGE_ENC:
                 self._sum(be.region(prep, "stat_enc2"))
             elif ph == _lib.PH_NODE_COMBINE:           # the layer's column statistics are complete here
