@@ -402,7 +402,7 @@ def run_training_step(device):
     def step():
         opt.zero_grad(set_to_none=True)
         out, _ = model(data)
-        loss = sum(mtmc_mpn.ops.cross_entropy(o, labels, weight=ce_weight) for o in out["classified_edges"])
+        loss = mtmc_mpn.cross_entropy_steps(out["classified_edges"], labels, weight=ce_weight)   # = the sum over the steps
         loss.backward()
         opt.step()
         return loss

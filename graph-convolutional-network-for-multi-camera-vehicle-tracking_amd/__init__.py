@@ -11,10 +11,10 @@ from .config import DEFAULT_ARCH, DEFAULT_GRAPH_NET_PARAMS, default_params  # no
 from .graph_build import build_graph  # noqa: F401
 from .postprocess import postprocess  # noqa: F401
 from . import ops  # noqa: F401
-from .ops import cross_entropy  # noqa: F401
+from .ops import cross_entropy, cross_entropy_steps  # noqa: F401
 from .feature_store import FeatureStore  # noqa: F401
 from .modules import (MLP, EdgeModel, MetaLayer, MLPGraphIndependent, MOTMPNet,  # noqa: F401
                       NodeModel)
 
 __all__ = ["MOTMPNet", "MetaLayer", "EdgeModel", "NodeModel", "MLPGraphIndependent", "MLP",
-           "DEFAULT_GRAPH_NET_PARAMS", "DEFAULT_ARCH", "default_params", "build_graph", "postprocess", "FeatureStore", "cross_entropy", "ops"]
+           "DEFAULT_GRAPH_NET_PARAMS", "DEFAULT_ARCH", "default_params", "build_graph", "postprocess", "FeatureStore", "cross_entropy", "cross_entropy_steps", "ops"]

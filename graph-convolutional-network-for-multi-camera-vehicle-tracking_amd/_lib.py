@@ -60,7 +60,8 @@ EXPORTS = ["mtmc_mpn_abi_version", "mtmc_mpn_last_error", "mtmc_mpn_workspace_by
            "mtmc_mpn_forward", "mtmc_mpn_run_phase", "mtmc_scatter_add", "mtmc_scatter_mean", "mtmc_scatter_max",
            "mtmc_mlp_layer_forward", "mtmc_mpn_train_workspace_bytes", "mtmc_mpn_backward", "mtmc_graph_workspace_bytes",
            "mtmc_build_graph", "mtmc_postprocess_workspace_bytes", "mtmc_postprocess",
-           "mtmc_cross_entropy_forward", "mtmc_cross_entropy_backward", "mtmc_mpn_backward_steps", "mtmc_linear_raw", "mtmc_edge_confusion",
+           "mtmc_cross_entropy_forward", "mtmc_cross_entropy_backward",
+           "mtmc_cross_entropy_steps_forward", "mtmc_cross_entropy_steps_backward", "mtmc_mpn_backward_steps", "mtmc_linear_raw", "mtmc_edge_confusion",
            "mtmc_linear_presplit_raw"]
 
 _lib = None
@@ -111,6 +112,12 @@ def load() -> C.CDLL:
     lib.mtmc_cross_entropy_backward.restype = C.c_int32
     lib.mtmc_cross_entropy_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
                                                 C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mtmc_cross_entropy_steps_forward.restype = C.c_int32
+    lib.mtmc_cross_entropy_steps_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                                     C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mtmc_cross_entropy_steps_backward.restype = C.c_int32
+    lib.mtmc_cross_entropy_steps_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                                      C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mtmc_postprocess_workspace_bytes.restype = C.c_size_t
     lib.mtmc_postprocess_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int64]
     lib.mtmc_postprocess.restype = C.c_int32

@@ -22,12 +22,12 @@ __device__ __forceinline__ void ce_row(const float* x, int C, float (&p)[MTMC_MA
 
 __global__ __launch_bounds__(256) void ce_forward_kernel(const float* logits, const int64_t* labels, const float* weight,
                                                          int64_t n, int C, int64_t ignore_index, float* per_sample,
-                                                         double* sums) {
+                                                         double* sums, int64_t period) {
   __shared__ double red[2 * 4];
   double acc[2] = {0, 0};
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthreads) {
-    const int64_t y = labels[i];
+    const int64_t y = labels[period ? i % period : i];    // period: the same labels for every classified step
     float l = 0.f, w = 0.f;
     if (y != ignore_index && y >= 0 && y < C) {
       float x[MTMC_MAX_CLASSES], p[MTMC_MAX_CLASSES], lse;
@@ -45,21 +45,22 @@ __global__ __launch_bounds__(256) void ce_forward_kernel(const float* logits, co
 }
 
 // totals to sums[0..1]; loss = mean or sum (one thread: 32 additions)
-__global__ void ce_finalize_kernel(double* sums, int mode, float* loss_out) {
+__global__ void ce_finalize_kernel(double* sums, int mode, float* loss_out, double scale) {
   double s1 = 0, s2 = 0;
   for (int r = 0; r < kStatRep; ++r) { s1 += sums[r * 2]; s2 += sums[r * 2 + 1]; }
   sums[0] = s1; sums[1] = s2;
-  if (loss_out) loss_out[0] = (float)(mode == 0 ? s1 / s2 : s1);
+  if (loss_out) loss_out[0] = (float)(mode == 0 ? scale * s1 / s2 : s1);
 }
 
 // mode: 0 = mean, 1 = sum, 2 = none (grad is [n] then)
 __global__ __launch_bounds__(256) void ce_backward_kernel(const float* logits, const int64_t* labels, const float* weight,
                                                           int64_t n, int C, int64_t ignore_index, int mode,
-                                                          const float* grad, const double* sums, float* d_logits) {
-  const float g_all = mode == 0 ? (float)((double)grad[0] / sums[1]) : (mode == 1 ? grad[0] : 0.f);
+                                                          const float* grad, const double* sums, float* d_logits,
+                                                          int64_t period, double scale) {
+  const float g_all = mode == 0 ? (float)(scale * (double)grad[0] / sums[1]) : (mode == 1 ? grad[0] : 0.f);
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthreads) {
-    const int64_t y = labels[i];
+    const int64_t y = labels[period ? i % period : i];
     float d[MTMC_MAX_CLASSES] = {0.f, 0.f, 0.f, 0.f};
     if (y != ignore_index && y >= 0 && y < C) {
       float x[MTMC_MAX_CLASSES], p[MTMC_MAX_CLASSES], lse;
@@ -122,8 +123,40 @@ int32_t mtmc_cross_entropy_forward(const float* logits, const int64_t* labels, c
   if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * mtmc::kStatRep, s) != hipSuccess) return MTMC_E_HIP;
   if (n > 0)
     hipLaunchKernelGGL(mtmc::ce_forward_kernel, dim3(mtmc::ce_grid(n)), dim3(256), 0, s, logits, labels, weight, n,
-                       n_classes, ignore_index, per_sample, sums);
-  hipLaunchKernelGGL(mtmc::ce_finalize_kernel, dim3(1), dim3(1), 0, s, sums, mode, loss_out);
+                       n_classes, ignore_index, per_sample, sums, (int64_t)0);
+  hipLaunchKernelGGL(mtmc::ce_finalize_kernel, dim3(1), dim3(1), 0, s, sums, mode, loss_out, 1.0);
+  return hipGetLastError() == hipSuccess ? MTMC_OK : MTMC_E_HIP;
+}
+
+// The training loop's `sum(criterion(step, labels) for step in outputs['classified_edges'])` (reference train.py:118-138:
+// every classified step against the SAME labels) in one pass over the [n_steps][n][C] logits block the forward emits:
+// with equal labels the weight sums of the steps are equal, so sum_s mean_s = n_steps * (sum of all terms / sum of all
+// weights).  mode 0 = mean per step (then summed), 1 = sum.
+int32_t mtmc_cross_entropy_steps_forward(const float* logits, const int64_t* labels, const float* weight, int64_t n,
+                                         int32_t n_classes, int32_t n_steps, int64_t ignore_index, int32_t mode,
+                                         double* sums, float* loss_out, void* stream) {
+  if (!logits || !labels || !sums || n < 0 || n_steps < 1 || n_classes < 1 || n_classes > MTMC_MAX_CLASSES) return MTMC_E_ARG;
+  if (mode < 0 || mode > 1 || (n_classes == 2 && ((uintptr_t)logits & 7))) return MTMC_E_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * mtmc::kStatRep, s) != hipSuccess) return MTMC_E_HIP;
+  if (n > 0)
+    hipLaunchKernelGGL(mtmc::ce_forward_kernel, dim3(mtmc::ce_grid(n * n_steps)), dim3(256), 0, s, logits, labels, weight,
+                       n * n_steps, n_classes, ignore_index, (float*)nullptr, sums, n);
+  hipLaunchKernelGGL(mtmc::ce_finalize_kernel, dim3(1), dim3(1), 0, s, sums, mode, loss_out, (double)n_steps);
+  return hipGetLastError() == hipSuccess ? MTMC_OK : MTMC_E_HIP;
+}
+
+int32_t mtmc_cross_entropy_steps_backward(const float* logits, const int64_t* labels, const float* weight, int64_t n,
+                                          int32_t n_classes, int32_t n_steps, int64_t ignore_index, int32_t mode,
+                                          const float* grad, const double* sums, float* d_logits, void* stream) {
+  if (!logits || !labels || !grad || !sums || !d_logits || n < 0 || n_steps < 1 || n_classes < 1 ||
+      n_classes > MTMC_MAX_CLASSES || mode < 0 || mode > 1)
+    return MTMC_E_ARG;
+  if (n_classes == 2 && (((uintptr_t)logits & 7) || ((uintptr_t)d_logits & 7))) return MTMC_E_ARG;
+  if (n > 0)
+    hipLaunchKernelGGL(mtmc::ce_backward_kernel, dim3(mtmc::ce_grid(n * n_steps)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), logits, labels, weight, n * n_steps, n_classes, ignore_index, mode,
+                       grad, sums, d_logits, n, (double)n_steps);
   return hipGetLastError() == hipSuccess ? MTMC_OK : MTMC_E_HIP;
 }
 
@@ -135,7 +168,7 @@ int32_t mtmc_cross_entropy_backward(const float* logits, const int64_t* labels, 
   if (n_classes == 2 && (((uintptr_t)logits & 7) || ((uintptr_t)d_logits & 7))) return MTMC_E_ARG;
   if (n > 0)
     hipLaunchKernelGGL(mtmc::ce_backward_kernel, dim3(mtmc::ce_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       logits, labels, weight, n, n_classes, ignore_index, mode, grad, sums, d_logits);
+                       logits, labels, weight, n, n_classes, ignore_index, mode, grad, sums, d_logits, (int64_t)0, 1.0);
   return hipGetLastError() == hipSuccess ? MTMC_OK : MTMC_E_HIP;
 }
 

@@ -161,6 +161,61 @@ def cross_entropy(input, target, weight=None, reduction: str = "mean", ignore_in
     return _CrossEntropy.apply(input, target.contiguous().long(), weight, _REDUCTIONS[reduction], int(ignore_index))
 
 
+class _CrossEntropySteps(torch.autograd.Function):
+    """The classified steps of one forward are consecutive [E, C] slices of one block: one pass over all of them."""
+
+    @staticmethod
+    def forward(ctx, target, weight, mode, ignore_index, *steps):
+        n, c = steps[0].shape
+        dev = steps[0].device
+        sums = torch.empty(2 * _lib.STAT_REPLICAS, dtype=torch.float64, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().mtmc_cross_entropy_steps_forward(
+                steps[0].data_ptr(), target.data_ptr(), weight.data_ptr() if weight is not None else None, n, c,
+                len(steps), ignore_index, mode, sums.data_ptr(), loss.data_ptr(), _stream(dev)))
+        ctx.save_for_backward(target, weight, sums, *steps)
+        ctx.mode, ctx.ignore_index = mode, ignore_index
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad):
+        target, weight, sums, *steps = ctx.saved_tensors
+        n, c = steps[0].shape
+        dev = steps[0].device
+        d = torch.empty((len(steps), n, c), dtype=torch.float32, device=dev)
+        g = grad.contiguous().float()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().mtmc_cross_entropy_steps_backward(
+                steps[0].data_ptr(), target.data_ptr(), weight.data_ptr() if weight is not None else None, n, c,
+                len(steps), ctx.ignore_index, ctx.mode, g.data_ptr(), sums.data_ptr(), d.data_ptr(), _stream(dev)))
+        return (None, None, None, None) + tuple(d[i] for i in range(len(steps)))
+
+
+def cross_entropy_steps(steps, target, weight=None, reduction: str = "mean", ignore_index: int = -100):
+    """`sum(cross_entropy(step, target, weight, reduction) for step in steps)` -- the training loop's loss over
+    `outputs['classified_edges']` (reference train.py:118-138) -- in ONE pass when the steps are the consecutive slices
+    of the logits block a forward of this package returns (4 launches instead of 4 per step); any other list of
+    tensors is summed step by step."""
+    steps = list(steps)
+    if not steps:
+        raise ValueError("cross_entropy_steps: no classified steps")
+    if reduction not in ("mean", "sum"):
+        raise ValueError("cross_entropy_steps: reduction must be 'mean' or 'sum'")
+    s0 = steps[0]
+    block = (s0.dim() == 2 and s0.dtype == torch.float32 and s0.is_cuda and target.is_cuda and s0.shape[1] <= 4
+             and target.shape == s0.shape[:1]
+             and all(t.shape == s0.shape and t.dtype == s0.dtype and t.device == s0.device and t.is_contiguous()
+                     and t.data_ptr() == s0.data_ptr() + i * s0.numel() * 4 for i, t in enumerate(steps)))
+    if not block or len(steps) == 1:
+        return sum(cross_entropy(t, target, weight=weight, reduction=reduction, ignore_index=ignore_index) for t in steps)
+    if weight is not None:
+        weight = weight.to(device=s0.device, dtype=torch.float32).contiguous()
+        if weight.numel() != s0.shape[1]:
+            raise RuntimeError("mtmc_mpn.cross_entropy_steps: weight must have one entry per class")
+    return _CrossEntropySteps.apply(target.contiguous().long(), weight, _REDUCTIONS[reduction], int(ignore_index), *steps)
+
+
 def edge_confusion(logits, labels):
     """int64 tensor [TP, FP, TN, FN] (on the device) of `argmax(logits, 1) == 1` against 0/1 `labels`; e.g.
     FPR = FP / (FP + TN) as in train.py:100-102.  No host synchronisation."""

@@ -245,6 +245,17 @@ int32_t mtmc_cross_entropy_backward(const float* logits, const int64_t* labels, 
                                     int32_t n_classes, int64_t ignore_index, int32_t mode, const float* grad,
                                     const double* sums, float* d_logits, void* stream);
 
+/* sum over the classified steps of cross_entropy(step, labels) in one pass (the training loop's loss, reference
+ * train.py:118-138): logits = the contiguous [n_steps][n][n_classes] block of one forward, labels [n] shared by the steps.
+ * mode 0 = mean per step, 1 = sum; sums as above (of all steps together); loss_out[0] = the summed loss.
+ * backward: d_logits [n_steps][n][n_classes] for grad[0] = d loss. */
+int32_t mtmc_cross_entropy_steps_forward(const float* logits, const int64_t* labels, const float* weight, int64_t n,
+                                         int32_t n_classes, int32_t n_steps, int64_t ignore_index, int32_t mode,
+                                         double* sums, float* loss_out, void* stream);
+int32_t mtmc_cross_entropy_steps_backward(const float* logits, const int64_t* labels, const float* weight, int64_t n,
+                                          int32_t n_classes, int32_t n_steps, int64_t ignore_index, int32_t mode,
+                                          const float* grad, const double* sums, float* d_logits, void* stream);
+
 /* counts[4] (int64, device) = {TP, FP, TN, FN} of argmax(logits [n][n_classes]) against 0/1 labels [n], in one pass:
  * the confusion counts the training / validation loops compute with boolean-mask indexing (reference train.py:98-107,
  * inference.py:20-67).  Labels other than 0 / 1 are skipped; prediction = (argmax == 1), first maximum on ties. */
