@@ -18,6 +18,12 @@ pytestmark = pytest.mark.gpu
 def _case(agg):
     import mtmc_mpn
     from mtmc_mpn import graphs
+    if agg.endswith("+big"):       # 5 003 nodes / 240k edges, random sorted graph (some rows empty): hundreds of workgroups
+        agg = agg[:-4]             # per node kernel and row ranges that start anywhere
+        d = graphs.stress_graph(5003, 120000, seed=8)
+        p = mtmc_mpn.default_params(num_enc_steps=2, num_class_steps=1)
+        p["node_agg_fn"] = agg
+        return d, p
     d = graphs.camera_graph((31, 24, 17, 29), seed=5)
     if agg.endswith("+gaps"):      # nodes without out-edges (still edge targets): at the front, inside, at the end
         agg = agg[:-5]
@@ -64,7 +70,8 @@ def _worker(rank, world, port, agg, snap, out_dir, own=False):
 
 @pytest.mark.parametrize("world,agg,snap,own", [(2, "sum", False, False), (2, "mean", True, False), (3, "max", False, False),
                                                 (3, "sum", True, False), (3, "mean+gaps", True, False),
-                                                (2, "max", True, True), (3, "sum+gaps", True, True)])
+                                                (2, "max", True, True), (3, "sum+gaps", True, True),
+                                                (3, "mean+big", True, True), (2, "sum+big", False, False)])
 def test_sharded_forward_on_the_gpu_kernels(world, agg, snap, own, tmp_path):
     import types
     import mtmc_mpn
