@@ -107,21 +107,24 @@ def main_distributed(args):
     if name != "s02":
         full = bench.make_workload("s02", device)
         n2, e2 = full.x.shape[0], full.edge_index.shape[1]
-        lo2, hi2 = mdist.even_ranges(n2, world)[rank]
         elo2, ehi2 = mdist.edge_ranges(full.edge_index[0], e2, world, snap_to_rows=True)[rank]
-        x2, ei2, ea2 = full.x[lo2:hi2].clone(), full.edge_index[:, elo2:ehi2].clone(), full.edge_attr[elo2:ehi2].clone()
+        ei2, ea2 = full.edge_index[:, elo2:ehi2].clone(), full.edge_attr[elo2:ehi2].clone()
+        rr2 = mdist.row_ranges_of(ei2)
+        own2 = rr2 is not None
+        lo2, hi2 = mdist.tile_rows(rr2, n2)[rank] if own2 else mdist.even_ranges(n2, world)[rank]
+        x2 = full.x[lo2:hi2].clone()
         params2 = mtmc_mpn.default_params(num_enc_steps=3, num_class_steps=1)
         torch.manual_seed(0)
         model2 = mtmc_mpn.MOTMPNet(copy.deepcopy(params2), None, ARCH).to(device).eval()
         with torch.no_grad():
             for _ in range(5):
-                mdist.sharded_forward(model2, x2, (lo2, hi2, n2), ei2, ea2, e2)
+                mdist.sharded_forward(model2, x2, (lo2, hi2, n2), ei2, ea2, e2, row_ranges=rr2, own_rows=own2)
             torch.cuda.synchronize(device)
             dist.barrier()
             t0 = time.perf_counter()
             reps2 = 50
             for _ in range(reps2):
-                mdist.sharded_forward(model2, x2, (lo2, hi2, n2), ei2, ea2, e2)
+                mdist.sharded_forward(model2, x2, (lo2, hi2, n2), ei2, ea2, e2, row_ranges=rr2, own_rows=own2)
             torch.cuda.synchronize(device)
             dist.barrier()
             t2 = torch.tensor([(time.perf_counter() - t0) / reps2], dtype=torch.float64, device=device)
