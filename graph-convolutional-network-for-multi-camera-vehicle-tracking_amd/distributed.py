@@ -114,7 +114,7 @@ class ShardedForward:
                 h[rlo:rhi] = parts[r][:rhi - rlo].to(h.device)
 
     def __call__(self, x_local, node_range, edge_index_local, edge_attr_local, n_edges_total, row_ranges=None,
-                 own_rows=False):
+                 own_rows=False, replicate_h=True):
         """x_local: rows [node_range[0], node_range[1]) of x; node_range = (lo, hi, N).
         edge_index_local / edge_attr_local: this rank's edge slice (global node ids).
         row_ranges: per rank, the node range [lo, hi) that contains ALL source rows of its edge slice and no source
@@ -124,7 +124,9 @@ class ShardedForward:
         node state -- plus the final node state once, for the replicated output.  Without it the aggregated state is
         all-reduced every round and every rank projects every node.
         own_rows (needs row_ranges): the rank ENCODES the node rows it projects -- node_range[:2] is its entry of
-        `tile_rows(row_ranges, N)` instead of the even split -- so the encoded state h0 needs no exchange either."""
+        `tile_rows(row_ranges, N)` instead of the even split -- so the encoded state h0 needs no exchange either.
+        replicate_h=False (with row_ranges): skip the final all-gather; the returned node state is then valid only in the
+        rank's own rows `tile_rows(row_ranges, N)[rank]` (the callers of the reference never read it: `outputs, _ = ...`)."""
         be, spec = self.backend, self.spec
         world = dist.get_world_size(self.group)
         rank = dist.get_rank(self.group)
@@ -179,7 +181,7 @@ class ShardedForward:
                 if not local_rows:
                     (self._max if spec.agg == "max" else self._sum)(be.region(prep, "agg", arg))
         logits, h = be.outputs(prep)
-        if local_rows and (spec.num_enc_steps > 0 or own_rows):   # the replicated output: every rank's rows of the final state
+        if local_rows and replicate_h and (spec.num_enc_steps > 0 or own_rows):   # every rank's rows of the final state
             self._gather_rows(h, row_ranges, rank, world)
         return logits, h
 
@@ -206,12 +208,13 @@ def row_ranges_of(edge_index_local, group=None):
 
 
 def sharded_forward(module, x_local, node_range, edge_index_local, edge_attr_local, n_edges_total, group=None,
-                    row_ranges=None, own_rows=False):
+                    row_ranges=None, own_rows=False, replicate_h=True):
     """Convenience wrapper: one edge-partitioned forward of a (HIP-backed) MOTMPNet on this rank's shard.
-    Returns ({'classified_edges': [local logits]}, h) with h replicated on every rank."""
+    Returns ({'classified_edges': [local logits]}, h) with h replicated on every rank (unless replicate_h=False)."""
     from . import engine
     if module._engine is None:
         module._engine = engine.ForwardEngine(module)
     logits, h = ShardedForward(module._engine, module.spec, group)(x_local, node_range, edge_index_local,
-                                                                  edge_attr_local, n_edges_total, row_ranges, own_rows)
+                                                                  edge_attr_local, n_edges_total, row_ranges, own_rows,
+                                                                  replicate_h)
     return {"classified_edges": logits}, h

@@ -134,6 +134,11 @@ def _gap_worker(rank, world, port, out_dir, own, L):
         with torch.no_grad():
             logits, h = mdist.ShardedForward(CpuPhaseBackend(sd, m.spec), m.spec)(
                 d.x[lo:hi], (lo, hi, n), d.edge_index[:, elo:ehi], d.edge_attr[elo:ehi], e, rr, own)
+            # the same without the final all-gather: the rank's own rows must already be final
+            _, h_own = mdist.ShardedForward(CpuPhaseBackend(sd, m.spec), m.spec)(
+                d.x[lo:hi], (lo, hi, n), d.edge_index[:, elo:ehi], d.edge_attr[elo:ehi], e, rr, own, replicate_h=False)
+        tlo, thi = mdist.tile_rows(rr, n)[rank]
+        assert torch.equal(h_own[tlo:thi], h[tlo:thi])
         torch.save({"logits": [l.clone() for l in logits], "h": h.clone()}, os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
