@@ -71,6 +71,24 @@ def main_distributed(args):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     sec = float(t.item())
 
+    # side measurement: the same forward with the node state left sharded (no final [N,32] all-gather) -- the callers of
+    # the reference never read latent_node_feats; `value` above is the forward WITH the replicated output
+    sec_sharded_h = None
+    if rr is not None:
+        with torch.no_grad():
+            for _ in range(2):
+                mdist.sharded_forward(model, x_loc, (lo, hi, n), ei_loc, ea_loc, e, row_ranges=rr, own_rows=own, replicate_h=False)
+            torch.cuda.synchronize(device)
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                mdist.sharded_forward(model, x_loc, (lo, hi, n), ei_loc, ea_loc, e, row_ranges=rr, own_rows=own, replicate_h=False)
+            torch.cuda.synchronize(device)
+            dist.barrier()
+            t2 = torch.tensor([(time.perf_counter() - t0) / args.steps], dtype=torch.float64, device=device)
+        dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        sec_sharded_h = float(t2.item())
+
     # per-phase split on this rank (kernels vs collectives), a few extra iterations with events
     eng = model._engine
     split = {"kernels_ms": 0.0, "collectives_ms": 0.0}
@@ -152,6 +170,7 @@ def main_distributed(args):
                                  "headline"),
                 "forward_algorithmic": {"bytes": b_fwd, "GBps": b_fwd / sec / 1e9,
                                         "frac_of_aggregate_hbm_peak": b_fwd / sec / 1e9 / (bench.HBM_PEAK_GBS * world)},
-                "rank0_split": split}
+                "rank0_split": split,
+                "ms_per_step_with_sharded_node_state": None if sec_sharded_h is None else sec_sharded_h * 1e3}
         print(json.dumps(line))
     dist.destroy_process_group()
