@@ -96,10 +96,10 @@ class ShardedForward:
         """Every rank holds COMPLETE rows [lo_r, hi_r) of h (row-snapped shards of a row-sorted list): exchange them
         with one all-gather (half the bytes of the all-reduce they make unnecessary), padded to the longest range."""
         longest = max(hi - lo for lo, hi in row_ranges)
-        if longest == 0:
+        if longest == 0 or world == 1:
             return
         lo, hi = row_ranges[rank]
-        send = h.new_zeros((longest, h.shape[1]))
+        send = h.new_empty((longest, h.shape[1]))      # the padding rows are never copied out
         send[:hi - lo] = h[lo:hi]
         if dist.get_backend(self.group) == "nccl":
             recv = h.new_empty((world * longest, h.shape[1]))
