@@ -16,11 +16,11 @@ constexpr int kProjOut = 40;     // 4 (Pr) + 4 (Pc) + 32 (Q)
 
 __global__ __launch_bounds__(256) void node_proj_kernel(NodeProjParams p) {
   __shared__ float wt[64 * kProjOut];              // [k][j], k < hn
-  __shared__ float hs[kProjNodes * 65];            // [node][k], row stride hn+1
+  __shared__ float hs[kProjNodes * 66];            // [node][k], row stride hn+2 (see the k loop)
   __shared__ float ys[kH], yt[kH];                 // BatchNorm affine of the encoder's last layer (fused round 0)
   __shared__ EdgeEncAffine enc_af;
   __shared__ double scratch[kStatAttr + kStatEnc2];
-  const int hn = p.hn, ldh = hn + 1;
+  const int hn = p.hn, ldh = hn + 2;
   for (int i = threadIdx.x; i < hn * kProjOut; i += blockDim.x) {
     const int kk = i / kProjOut, j = i % kProjOut;
     float w;
@@ -62,8 +62,10 @@ __global__ __launch_bounds__(256) void node_proj_kernel(NodeProjParams p) {
     }
     __syncthreads();
     float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    const int kq = hn >> 1;
-    for (int kk = kh * kq; kk < (kh + 1) * kq; ++kk) {
+    // a lane pair takes the even / the odd k: with row stride hn+2 the eight (node, k) words and the sixteen weights a
+    // wave reads per step sit on different banks (halves of the k range, 32 apart, met on the same banks: 42 % of this
+    // kernel's LDS cycles were conflicts at config 4)
+    for (int kk = kh; kk < hn; kk += 2) {
       const float hv = hs[nl * ldh + kk];
 #pragma unroll
       for (int i = 0; i < 5; ++i) acc[i] = fmaf(hv, wt[kk * kProjOut + part + 8 * i], acc[i]);
