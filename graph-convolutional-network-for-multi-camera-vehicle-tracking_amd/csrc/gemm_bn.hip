@@ -18,6 +18,9 @@
 // are in flight while the current one is multiplied.
 #include "kernels.h"
 #include <stdlib.h>
+#include <mutex>
+#include <set>
+#include <utility>
 
 namespace mtmc {
 
@@ -502,10 +505,15 @@ __global__ __launch_bounds__(256) void gemm_bn_f16x3_kernel(GemmParams p, int ti
     typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
     const float x0 = v.x * scale, x1 = v.y * scale, x2 = v.z * scale, x3 = v.w * scale;
     // two-piece split with truncating conversions (v_cvt_pkrtz_f16_f32): h1 = rtz(x), h2 = rtz(x - h1); the
-    // residual x - h1 is exact, 22 mantissa bits are kept.  Deliberately NOT `(_Float16)x`: hipcc 7.2 lowers that
-    // to v_cvt_pk_f16_f32 / v_fma_mix{lo,hi}_f16 sequences which, with two or more of these workgroups resident on
-    // a CU, sporadically left zeros in the pieces written by lanes 48-63 (reproducer: tools/dbg_gemm.py)
-#ifdef MTMC_F16_CVT_RNE   // reproduces the hazard: make clean && make EXTRA=-DMTMC_F16_CVT_RNE && python tools/dbg_gemm.py 9000 2048 1024
+    // residual x - h1 is exact, 22 mantissa bits are kept.
+    // Round 1 saw wrong results with the `(_Float16)x` spelling of this split and blamed the conversion instructions.
+    // Root cause (round 2; stand-alone reproducer tools/hazard/pk_probe.hip): for that spelling hipcc's
+    // SLP vectoriser multiplies .z/.w by the scale with `v_pk_mul_f32 / v_pk_fma_f32 D, A, S op_sel:[0,1(,0)]` (the scale
+    // sits in the ODD register of the pair read from sc[]), and on gfx950 a packed-fp32 op whose LOW lane selects the
+    // HIGH dword of a source returns 0 in that lane for lanes 48-63 while the wave's own MFMAs are still in flight and
+    // a second wave shares the SIMD.  Not a property of this source line, so the guard is in the build: tools/check_isa.py
+    // (run by the Makefile and by tests/test_isa_lint.py) rejects any MFMA kernel that contains the form.
+#ifdef MTMC_F16_CVT_RNE   // the spelling that made hipcc emit the failing form (tools/hazard/ab_build.sh builds it on the side)
     {
       const float xs[4] = {x0, x1, x2, x3};
       f16x4 q1r, q2r;
@@ -665,8 +673,21 @@ __global__ __launch_bounds__(256) void gemm_bn_f16x3_kernel(GemmParams p, int ti
   }
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is per device: remember it per (kernel, device), under a lock.
+static bool allow_big_lds(const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> g(mu);
+  if (done.count({fn, dev})) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+  done.insert({fn, dev});
+  return true;
+}
+
 template <int TM, int TN, int BK>
-static void launch_f16x3(const GemmParams& p, hipStream_t s) {
+static int launch_f16x3(const GemmParams& p, hipStream_t s) {
   constexpr int BM = 64 * TM, BN = 64 * TN, LDB = BK + 8;
   const int tiles_m = (int)((p.M + BM - 1) / BM), tiles_n = (p.Nout + BN - 1) / BN;
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
@@ -674,30 +695,22 @@ static void launch_f16x3(const GemmParams& p, hipStream_t s) {
   size_t lds = (size_t)2 * (BM + BN) * LDB * 2 + (size_t)(2 * (kc < kAffChunk ? kc : kAffChunk) + 12) * sizeof(float);
   const size_t epi = (size_t)4 * BN * sizeof(double);
   if (lds < epi) lds = epi;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bn_f16x3_kernel<TM, TN, BK>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    attr_set = true;
-  }
+  if (!allow_big_lds(reinterpret_cast<const void*>(gemm_bn_f16x3_kernel<TM, TN, BK>), 128 * 1024)) return MTMC_E_HIP;
   hipLaunchKernelGGL((gemm_bn_f16x3_kernel<TM, TN, BK>), dim3(grid, p.split_k), dim3(256), lds, s, p, tiles_m, tiles_n);
+  return MTMC_OK;
 }
 
 template <int TM, int TN, int BK>
-static void launch_bf16x6(const GemmParams& p, hipStream_t s) {
+static int launch_bf16x6(const GemmParams& p, hipStream_t s) {
   constexpr int BM = 64 * TM, BN = 64 * TN, LDB = BK + 8;
   const int tiles_m = (int)((p.M + BM - 1) / BM), tiles_n = (p.Nout + BN - 1) / BN;
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
   size_t lds = (size_t)3 * (BM + BN) * LDB * 2 + (size_t)2 * (p.K / p.split_k) * sizeof(float);
   const size_t epi = (size_t)4 * BN * sizeof(double);
   if (lds < epi) lds = epi;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bn_bf16x6_kernel<TM, TN, BK>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  if (!allow_big_lds(reinterpret_cast<const void*>(gemm_bn_bf16x6_kernel<TM, TN, BK>), 160 * 1024)) return MTMC_E_HIP;
   hipLaunchKernelGGL((gemm_bn_bf16x6_kernel<TM, TN, BK>), dim3(grid, p.split_k), dim3(256), lds, s, p, tiles_m, tiles_n);
+  return MTMC_OK;
 }
 
 // Second half of a split-K layer: Y = bias + sum of the K-slices' slabs (fixed order => reproducible),
@@ -829,14 +842,16 @@ int launch_gemm_bn(const GemmParams& p, hipStream_t s, int which) {
     static const bool fp32_only = getenv("MTMC_GEMM_FP32") != nullptr;
     static const bool no_f16 = getenv("MTMC_GEMM_NO_F16") != nullptr;
     const bool f16 = p.amax_a && p.amax_w && !fp32_only && !no_f16;
-    if (cfg == 2 && f16 && p.K % 64 == 0) launch_f16x3<2, 2, 64>(q, s);
-    else if (cfg == 2 && f16) launch_f16x3<2, 2, 32>(q, s);
-    else if (cfg == 1 && f16 && (p.K / q.split_k) % 64 == 0) launch_f16x3<1, 1, 64>(q, s);
-    else if (cfg == 1 && f16) launch_f16x3<1, 1, 32>(q, s);
-    else if (cfg == 2 && !fp32_only) launch_bf16x6<2, 2, 32>(q, s);
+    int rc = MTMC_OK;
+    if (cfg == 2 && f16 && p.K % 64 == 0) rc = launch_f16x3<2, 2, 64>(q, s);
+    else if (cfg == 2 && f16) rc = launch_f16x3<2, 2, 32>(q, s);
+    else if (cfg == 1 && f16 && (p.K / q.split_k) % 64 == 0) rc = launch_f16x3<1, 1, 64>(q, s);
+    else if (cfg == 1 && f16) rc = launch_f16x3<1, 1, 32>(q, s);
+    else if (cfg == 2 && !fp32_only) rc = launch_bf16x6<2, 2, 32>(q, s);
     else if (cfg == 2) launch_cfg<2, 2, 32>(q, s);
     else if ((p.K / q.split_k) % 64 == 0) launch_cfg<1, 1, 64>(q, s);
     else launch_cfg<1, 1, 32>(q, s);
+    if (rc != MTMC_OK) return rc;
   }
   if ((which & 2) && q.split_k > 1) launch_combine(q, s);
   return MTMC_OK;
