@@ -128,6 +128,11 @@ class ForwardEngine:
         e = edge_index.shape[1]
         node_lo, node_hi = (0, x.shape[0]) if node_range is None else node_range[:2]
         n = x.shape[0] if node_range is None else node_range[2]
+        # the kernels index x by (node - node_lo): a slice of the wrong height would be read out of bounds on the device
+        if not (0 <= node_lo <= node_hi <= n) or x.shape[0] != node_hi - node_lo:
+            raise RuntimeError(f"mtmc_mpn: node_range {(node_lo, node_hi, n)} does not describe the {x.shape[0]} rows of x")
+        if row_range is not None and not (0 <= int(row_range[0]) <= int(row_range[1]) <= n):
+            raise RuntimeError(f"mtmc_mpn: row_range {tuple(row_range)} is not inside [0, {n}]")
         if x.stride(1) != 1 or x.stride(0) % 4 != 0:
             x = x.contiguous()
         if not edge_attr.is_contiguous():

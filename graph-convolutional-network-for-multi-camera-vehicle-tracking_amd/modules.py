@@ -143,6 +143,9 @@ class MOTMPNet(nn.Module):
             with torch.cuda.stream(side):                 # warm-up outside the capture: lazy library setup
                 self.forward(data)
             torch.cuda.current_stream(dev).wait_stream(side)
+            side.synchronize()
+            # the warm-up's workspace is keyed by the side stream, which nothing uses again: drop it (it leaked before)
+            self._engine._ws.pop((dev, side.cuda_stream), None)
             before = dict(self._engine._ws)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 import mtmc_mpn
-from golden_util import ARCH, Case, case_names
+from golden_util import ARCH, Case, case_names, sha
 from mtmc_mpn import graphs
 
 pytestmark = pytest.mark.gpu
@@ -62,15 +62,17 @@ def test_forward_matches_golden_and_oracle(name):
     logits = out["classified_edges"]
     assert isinstance(out, dict) and len(logits) == c.meta["n_out"] == len(ora["classified_edges"])
     assert h.shape == (c.meta["N"], 32) and h.dtype == torch.float32 and h.is_cuda
-    same_inputs = c.inputs_match_reference_run(d)
+    # x and edge_index are seeded integers / randn: identical on every host.  edge_attr (and normalize(x)) may differ from
+    # the reference run in the last bit when this host's CPU takes another vector path -- irrelevant at 1e-4, so the
+    # golden comparison below is unconditional (round 1 skipped it in that case).
+    assert sha(d.edge_index) == c.meta["input_sha"]["edge_index"]
     for i, lg in enumerate(logits):
         assert lg.shape == (c.meta["E"], 2) and lg.dtype == torch.float32 and lg.is_cuda
         got = lg.cpu()
         err_oracle = (got - ora["classified_edges"][i]).abs().max().item()
         assert err_oracle <= LOGIT_TOL, f"{name}[{i}] vs CPU oracle: {err_oracle:.3e}"
-        if same_inputs:
-            err_gold = (got[c.sub_idx] - c.logits(i)).abs().max().item()
-            assert err_gold <= LOGIT_TOL, f"{name}[{i}] vs golden (reference): {err_gold:.3e}"
+        err_gold = (got[c.sub_idx] - c.logits(i)).abs().max().item()
+        assert err_gold <= LOGIT_TOL, f"{name}[{i}] vs golden (reference): {err_gold:.3e}"
         err64 = (got.double() - ora64["classified_edges"][i]).abs().max().item()
         ref_err64 = (ora["classified_edges"][i].double() - ora64["classified_edges"][i]).abs().max().item()
         assert err64 <= max(4 * ref_err64, 2e-5), f"{name}[{i}]: |gpu-fp64| {err64:.2e} vs reference's own {ref_err64:.2e}"
