@@ -57,7 +57,7 @@ F_DETERMINISTIC, F_GLOBAL_DEG, F_FORK = 1, 4, 2
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmtmc_mpn.so")
 EXPORTS = ["mtmc_mpn_abi_version", "mtmc_mpn_last_error", "mtmc_mpn_workspace_bytes", "mtmc_mpn_workspace_layout",
-           "mtmc_mpn_forward", "mtmc_mpn_run_phase", "mtmc_scatter_add", "mtmc_scatter_mean", "mtmc_scatter_max",
+           "mtmc_mpn_forward", "mtmc_mpn_run_phase", "mtmc_scatter_add", "mtmc_scatter_add_i64", "mtmc_scatter_mean", "mtmc_scatter_max",
            "mtmc_mlp_layer_forward", "mtmc_mpn_train_workspace_bytes", "mtmc_mpn_backward", "mtmc_graph_workspace_bytes",
            "mtmc_build_graph", "mtmc_postprocess_workspace_bytes", "mtmc_postprocess",
            "mtmc_cross_entropy_forward", "mtmc_cross_entropy_backward",
@@ -126,7 +126,7 @@ def load() -> C.CDLL:
                                      C.c_size_t, C.c_void_p]
     lib.mtmc_mpn_run_phase.restype = C.c_int32
     lib.mtmc_mpn_run_phase.argtypes = [C.POINTER(Model), C.POINTER(Call), C.c_int32, C.c_int32]
-    for name in ("mtmc_scatter_add",):
+    for name in ("mtmc_scatter_add", "mtmc_scatter_add_i64"):
         getattr(lib, name).restype = C.c_int32
         getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     lib.mtmc_scatter_mean.restype = C.c_int32

@@ -114,6 +114,15 @@ int32_t mtmc_scatter_add(const float* src, const int64_t* index, int64_t n_src, 
                          float* out, void* stream) {
   return scatter_common(src, index, n_src, n_cols, dim_size, out, nullptr, nullptr, 0, stream);
 }
+int32_t mtmc_scatter_add_i64(const int64_t* src, const int64_t* index, int64_t n_src, int64_t n_cols, int64_t dim_size,
+                             int64_t* out, void* stream) {
+  if (n_src < 0 || n_cols < 1 || dim_size < 0 || !out || (n_src > 0 && (!src || !index)))
+    return fail(MTMC_E_ARG, "bad scatter arguments");
+  if (dim_size == 0) return MTMC_OK;
+  mtmc::launch_scatter_add_i64(src, index, n_src, n_cols, dim_size, out, static_cast<hipStream_t>(stream));
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MTMC_OK : fail(MTMC_E_HIP, "scatter launch failed: %s", hipGetErrorString(e));
+}
 int32_t mtmc_scatter_mean(const float* src, const int64_t* index, int64_t n_src, int64_t n_cols, int64_t dim_size,
                           float* out, float* count_scratch, void* stream) {
   return scatter_common(src, index, n_src, n_cols, dim_size, out, count_scratch, nullptr, 1, stream);

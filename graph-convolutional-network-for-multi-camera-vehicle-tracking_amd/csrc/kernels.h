@@ -126,6 +126,9 @@ int gemm_plan(int64_t M, int K, int Nout, int* split_k);
 void launch_scatter(const float* src, const int64_t* index, int64_t n_src, int64_t n_cols, int64_t dim_size,
                     float* out, float* count, int64_t* arg_out, int mode, hipStream_t s);
 
+void launch_scatter_add_i64(const int64_t* src, const int64_t* index, int64_t n_src, int64_t n_cols, int64_t dim_size,
+                            int64_t* out, hipStream_t s);
+
 size_t pp_workspace_bytes(int64_t n_nodes, int64_t n_edges, int64_t max_active);
 int launch_postprocess(const float* logits, const int64_t* row, const int64_t* col, int64_t idx_stride, int64_t n_nodes,
                        int64_t n_edges, int num_cameras, int flags, int64_t max_active, float* prob1, int64_t* pred,

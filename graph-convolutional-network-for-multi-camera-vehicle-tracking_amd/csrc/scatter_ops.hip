@@ -72,6 +72,17 @@ __global__ void scatter_unkey_kernel(float* out, int64_t n) {
   }
 }
 
+// the 1-D integer call form of the post-processing (reference utils.py:173-174, :308-309): int64 in, int64 out, exact
+__global__ void scatter_add_i64_kernel(const int64_t* src, const int64_t* index, int64_t n_src, int64_t n_cols,
+                                       int64_t dim_size, int64_t* out) {
+  const int64_t total = n_src * n_cols, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = index[i / n_cols];
+    if (r < 0 || r >= dim_size) continue;
+    atomicAdd(reinterpret_cast<unsigned long long*>(out) + r * n_cols + i % n_cols, (unsigned long long)src[i]);
+  }
+}
+
 static inline int sgrid(int64_t n) {
   const int64_t b = (n + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -101,6 +112,14 @@ void launch_scatter(const float* src, const int64_t* index, int64_t n_src, int64
                        mode == 1 ? count : nullptr);
   if (mode == 1)
     hipLaunchKernelGGL(scatter_div_kernel, dim3(sgrid(n_out)), dim3(256), 0, s, out, count, dim_size, n_cols);
+}
+
+void launch_scatter_add_i64(const int64_t* src, const int64_t* index, int64_t n_src, int64_t n_cols, int64_t dim_size,
+                            int64_t* out, hipStream_t s) {
+  hipLaunchKernelGGL(scatter_fill_i64_kernel, dim3(sgrid(dim_size * n_cols)), dim3(256), 0, s, out, dim_size * n_cols, (int64_t)0);
+  if (n_src * n_cols > 0)
+    hipLaunchKernelGGL(scatter_add_i64_kernel, dim3(sgrid(n_src * n_cols)), dim3(256), 0, s, src, index, n_src, n_cols,
+                       dim_size, out);
 }
 
 }  // namespace mtmc

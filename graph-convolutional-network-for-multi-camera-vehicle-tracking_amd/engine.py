@@ -25,61 +25,101 @@ def _check_param(p: torch.Tensor, dev) -> int:
     return p.data_ptr()
 
 
+def layer_slots(spec: MpnSpec):
+    """(struct slot, index or None, LayerSpec) for every layer, in mtmc_mpn_model order.  The flat parameter list every
+    entry point takes follows it: weight, bias, then BatchNorm gamma, beta where the layer has one."""
+    out = [("enc_node", i, l) for i, l in enumerate(spec.enc_node)]
+    out += [("enc_edge", i, l) for i, l in enumerate(spec.enc_edge)]
+    out += [("upd_edge", None, spec.upd_edge[0]), ("upd_node", None, spec.upd_node[0]), ("cls", None, spec.cls_edge[0])]
+    return out
+
+
+def module_layers(module):
+    """(slot, Linear, BatchNorm or None, LayerSpec) of a MOTMPNet module tree, in layer_slots order."""
+    m, s = module, module.spec
+    out = []
+    for i, layer in enumerate(s.enc_node):
+        out.append((("enc_node", i),) + _lin(m.encoder.node_mlp, layer) + (layer,))
+    for i, layer in enumerate(s.enc_edge):
+        out.append((("enc_edge", i),) + _lin(m.encoder.edge_mlp, layer) + (layer,))
+    out.append((("upd_edge", None),) + _lin(m.MPNet.edge_model.edge_mlp, s.upd_edge[0]) + (s.upd_edge[0],))
+    out.append((("upd_node", None),) + _lin(m.MPNet.node_model.node_mlp, s.upd_node[0]) + (s.upd_node[0],))
+    out.append((("cls", None),) + _lin(m.classifier.edge_mlp, s.cls_edge[0]) + (s.cls_edge[0],))
+    return out
+
+
+def ordered_params(module) -> List[torch.Tensor]:
+    """The module's parameters as the flat list torch.ops.mtmc_mpn.* take (layer_slots order)."""
+    out = []
+    for _, lin, bn, _ in module_layers(module):
+        out += [lin.weight, lin.bias]
+        if bn is not None:
+            out += [bn.weight, bn.bias]
+    return out
+
+
 class ForwardEngine:
-    def __init__(self, module):
-        self.module = module
-        self.spec: MpnSpec = module.spec
+    """Host side of the C ABI for one architecture (`MpnSpec`).  Constructed from a spec (parameters then come with
+    every call, as torch.ops.mtmc_mpn.* pass them) or from a module (its own parameters are the default)."""
+
+    def __init__(self, module_or_spec):
+        if isinstance(module_or_spec, MpnSpec):
+            self.module, self.spec = None, module_or_spec
+        else:
+            self.module, self.spec = module_or_spec, module_or_spec.spec
         self.lib = _lib.load()
         self._ws = {}
         self._layers = None             # param_layers(): the module tree is fixed after construction
+        self._slots = layer_slots(self.spec)
+        self._default_params = None
         self._ms_key, self._ms = None, None
+        self.flags = 0                  # MTMC_F_* for the calls this engine prepares (torch op argument)
 
     # -- parameters -> mtmc_mpn_model ------------------------------------------------------------
     def param_layers(self):
-        """(struct slot, Linear, BatchNorm or None, LayerSpec) for every layer, in mtmc_mpn_model order."""
-        if self._layers is not None:
-            return self._layers
-        m, s = self.module, self.spec
-        out = []
-        for i, layer in enumerate(s.enc_node):
-            out.append((("enc_node", i),) + _lin(m.encoder.node_mlp, layer) + (layer,))
-        for i, layer in enumerate(s.enc_edge):
-            out.append((("enc_edge", i),) + _lin(m.encoder.edge_mlp, layer) + (layer,))
-        out.append((("upd_edge", None),) + _lin(m.MPNet.edge_model.edge_mlp, s.upd_edge[0]) + (s.upd_edge[0],))
-        out.append((("upd_node", None),) + _lin(m.MPNet.node_model.node_mlp, s.upd_node[0]) + (s.upd_node[0],))
-        out.append((("cls", None),) + _lin(m.classifier.edge_mlp, s.cls_edge[0]) + (s.cls_edge[0],))
-        self._layers = out
-        return out
+        """(struct slot, Linear, BatchNorm or None, LayerSpec) for every layer of the bound module."""
+        if self._layers is None:
+            if self.module is None:
+                raise RuntimeError("mtmc_mpn: this engine was built from a spec; pass the parameter list explicitly")
+            self._layers = module_layers(self.module)
+        return self._layers
 
-    def model_struct(self, dev) -> _lib.Model:
-        # the struct only changes when a parameter's storage does: key it on the 34 device pointers
-        key = (dev,) + tuple(t.data_ptr() for _, lin, bn, _ in self.param_layers()
-                             for t in ((lin.weight, lin.bias) if bn is None else (lin.weight, lin.bias, bn.weight, bn.bias)))
+    def params(self) -> List[torch.Tensor]:
+        if self._default_params is None:
+            self._default_params = ordered_params(self.module) if self.module is not None else None
+        if self._default_params is None:
+            raise RuntimeError("mtmc_mpn: no parameters given")
+        return self._default_params
+
+    def model_struct(self, dev, params=None) -> _lib.Model:
+        params = self.params() if params is None else params
+        # the struct only changes when a parameter's storage does: key it on the device pointers
+        key = (dev,) + tuple(t.data_ptr() for t in params)
         if key == self._ms_key:
             return _lib.Model.from_buffer_copy(self._ms)
-        m, s = self.module, self.spec
+        s = self.spec
         out = _lib.Model()
-
-        def fill(dst, mlp, layer):
-            lin, bn = _lin(mlp, layer)
-            dst.weight, dst.bias = _check_param(lin.weight, dev), _check_param(lin.bias, dev)
-            dst.gamma = _check_param(bn.weight, dev) if bn is not None else None
-            dst.beta = _check_param(bn.bias, dev) if bn is not None else None
-            dst.in_dim, dst.out_dim = layer.in_dim, layer.out_dim
+        if len(s.enc_node) > _lib.MAX_ENC_LAYERS:
+            raise NotImplementedError("mtmc_mpn: node encoder deeper than 8 layers")
+        it = iter(params)
+        try:
+            for slot, idx, layer in self._slots:
+                dst = getattr(out, slot) if idx is None else getattr(out, slot)[idx]
+                w, b = next(it), next(it)
+                if tuple(w.shape) != (layer.out_dim, layer.in_dim) or tuple(b.shape) != (layer.out_dim,):
+                    raise RuntimeError(f"mtmc_mpn: parameter shapes of {slot}[{idx}] do not match the configuration")
+                dst.weight, dst.bias = _check_param(w, dev), _check_param(b, dev)
+                if layer.bn_slot is not None:
+                    dst.gamma, dst.beta = _check_param(next(it), dev), _check_param(next(it), dev)
+                else:
+                    dst.gamma = dst.beta = None
+                dst.in_dim, dst.out_dim = layer.in_dim, layer.out_dim
+        except StopIteration:
+            raise RuntimeError("mtmc_mpn: parameter list shorter than the configuration needs") from None
         out.dropout_enc = float(s.enc_node[0].dropout_p or 0.0)
         out.dropout_upd_edge = float(s.upd_edge[0].dropout_p or 0.0)
         out.dropout_upd_node = float(s.upd_node[0].dropout_p or 0.0)
-
-        if len(s.enc_node) > _lib.MAX_ENC_LAYERS:
-            raise NotImplementedError("mtmc_mpn: node encoder deeper than 8 layers")
         out.n_enc_layers = len(s.enc_node)
-        for i, layer in enumerate(s.enc_node):
-            fill(out.enc_node[i], m.encoder.node_mlp, layer)
-        for i, layer in enumerate(s.enc_edge):
-            fill(out.enc_edge[i], m.encoder.edge_mlp, layer)
-        fill(out.upd_edge, m.MPNet.edge_model.edge_mlp, s.upd_edge[0])
-        fill(out.upd_node, m.MPNet.node_model.node_mlp, s.upd_node[0])
-        fill(out.cls, m.classifier.edge_mlp, s.cls_edge[0])
         out.agg = _lib.AGG[s.agg]
         out.num_enc_steps, out.num_class_steps = s.num_enc_steps, s.num_class_steps
         out.reattach_nodes, out.reattach_edges = int(s.reattach_nodes), int(s.reattach_edges)
@@ -118,7 +158,7 @@ class ForwardEngine:
             raise RuntimeError("mtmc_mpn: edge_index must be int64")
 
     def prepare(self, x, edge_index, edge_attr, training=False, n_edges_total=None, node_range=None, tape=False,
-                seed=0, row_range=None):
+                seed=0, row_range=None, params=None, tape_ws=None):
         """Validate, allocate outputs/workspace and fill the two C structs of one call.
         `tape=True`: training-mode layout in a fresh workspace that the backward will read (kept by autograd).
         `row_range=(lo, hi)`: multi-GPU, row-complete edge shard -- project / take node statistics of these rows only
@@ -145,8 +185,10 @@ class ForwardEngine:
         h = torch.empty((n, s.node_dim), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-        model = self.model_struct(dev)
-        if tape:
+        model = self.model_struct(dev, params)
+        if tape_ws is not None:                        # backward: the tape the forward op returned
+            ws = tape_ws
+        elif tape:
             need = self.lib.mtmc_mpn_train_workspace_bytes(C.byref(model), n, e)
             if need == 0:
                 _lib.check(_lib.E_ARG)
@@ -169,7 +211,7 @@ class ForwardEngine:
         call.h_out = h.data_ptr()
         call.workspace, call.workspace_bytes = ws.data_ptr(), ws.numel()
         call.training, call.seed = (1 if tape else 0), int(seed) & 0xFFFFFFFFFFFFFFFF
-        call.flags = _lib.F_DETERMINISTIC if getattr(self.module, "deterministic", False) else 0
+        call.flags = int(self.flags) | (_lib.F_DETERMINISTIC if getattr(self.module, "deterministic", False) else 0)
         call.stream = stream
         keep = (x, edge_index, edge_attr)        # the structs hold raw pointers: keep the tensors alive
         return types.SimpleNamespace(model=model, call=call, ws=ws, logits=logits, h=h, n_out=n_out, n=n, e=e,
@@ -260,17 +302,8 @@ class ForwardEngine:
         return [prep.logits[i] for i in range(prep.n_out)], prep.h
 
     def __call__(self, x, edge_index, edge_attr, training=False) -> Tuple[List[torch.Tensor], torch.Tensor]:
-        needs_grad = torch.is_grad_enabled() and (
-            x.requires_grad or edge_attr.requires_grad or any(p.requires_grad for p in self.module.parameters()))
-        if needs_grad or training:
-            from . import autograd
-            return autograd.forward_with_tape(self, x, edge_index, edge_attr, training)
-        prep = self.prepare(x, edge_index, edge_attr, training)
-        with torch.cuda.device(prep.dev):
-            _lib.check(self.lib.mtmc_mpn_forward(C.byref(prep.model), C.byref(prep.call)))
-            if self.module.check_indices:
-                lay = self.layout(prep)
-                flags = prep.ws[lay.flags_off:lay.flags_off + 32].view(torch.int32).cpu()
-                if int(flags[1]) != 0:
-                    raise IndexError("mtmc_mpn: edge_index holds node ids outside [0, N)")
-        return [prep.logits[i] for i in range(prep.n_out)], prep.h
+        """The bound module's forward, through the registered op (torch.ops.mtmc_mpn.mp_forward)."""
+        if self.module is None:
+            raise RuntimeError("mtmc_mpn: engine built from a spec has no module to call")
+        out, h = self.module(types.SimpleNamespace(x=x, edge_index=edge_index, edge_attr=edge_attr))
+        return out["classified_edges"], h

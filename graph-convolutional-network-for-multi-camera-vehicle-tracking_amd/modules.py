@@ -16,6 +16,7 @@ from typing import Dict, List, Optional
 import torch
 from torch import nn
 
+from . import _lib as _lib_flags
 from . import config as _config
 from .config import LayerSpec, MpnSpec
 
@@ -133,11 +134,11 @@ class MOTMPNet(nn.Module):
         CPU time than the forward takes on the GPU; weights may change between replays (they are read in place)."""
         if self.training:
             raise RuntimeError("mtmc_mpn: capture() is for eval-mode inference")
-        from . import engine
-        if self._engine is None:
-            self._engine = engine.ForwardEngine(self)
+        from . import torch_ops
         dev = data.x.device
         with torch.no_grad():
+            self.forward(data)                            # engines exist from here on
+            op_engine = torch_ops.engine_for(self._config_key)
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):                 # warm-up outside the capture: lazy library setup
@@ -145,14 +146,14 @@ class MOTMPNet(nn.Module):
             torch.cuda.current_stream(dev).wait_stream(side)
             side.synchronize()
             # the warm-up's workspace is keyed by the side stream, which nothing uses again: drop it (it leaked before)
-            self._engine._ws.pop((dev, side.cuda_stream), None)
-            before = dict(self._engine._ws)
+            op_engine._ws.pop((dev, side.cuda_stream), None)
+            before = dict(op_engine._ws)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = self.forward(data)
             # the workspace the captured kernels write to must live exactly as long as the graph: take it out of the
             # engine's per-stream cache (a later, larger forward on that stream would otherwise replace and free it)
-            held = [self._engine._ws.pop(k) for k in list(self._engine._ws) if before.get(k) is not self._engine._ws[k]]
+            held = [op_engine._ws.pop(k) for k in list(op_engine._ws) if before.get(k) is not op_engine._ws[k]]
 
         def replay():
             graph.replay()
@@ -161,9 +162,23 @@ class MOTMPNet(nn.Module):
         return replay
 
     def forward(self, data):
-        from . import engine
+        """`outputs, latent_node_feats = mpn_model(data)` (reference inference.py:469, train.py:356): one call of the
+        registered op `torch.ops.mtmc_mpn.mp_forward`; under grad mode / `.train()` it records the tape its autograd
+        formula (`mp_backward`) consumes."""
+        from . import engine, torch_ops
         if self._engine is None:
             self._engine = engine.ForwardEngine(self)
+            self._config_key = torch_ops.config_key(self.model_params, self.arch)
+            self._params = engine.ordered_params(self)
         x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr
-        logits, h = self._engine(x, edge_index, edge_attr, training=self.training)
-        return {"classified_edges": logits}, h
+        self._engine.check_inputs(x, edge_index, edge_attr)
+        params = self._params
+        needs_grad = torch.is_grad_enabled() and (
+            x.requires_grad or edge_attr.requires_grad or any(p.requires_grad for p in params))
+        tape = bool(needs_grad or self.training)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if self.training else 0    # follows torch.manual_seed
+        flags = (_lib_flags.F_DETERMINISTIC if self.deterministic else 0) | \
+            (torch_ops.CHECK_INDICES if self.check_indices else 0)
+        logits, h, _ = torch.ops.mtmc_mpn.mp_forward(x, edge_index, edge_attr, params, self._config_key,
+                                                     self.training, seed, flags, tape)
+        return {"classified_edges": list(logits.unbind(0))}, h

@@ -17,63 +17,60 @@ import ctypes as C
 import torch
 
 from . import _lib
+from . import torch_ops  # noqa: F401  (registers torch.ops.mtmc_mpn.*)
 
 
 def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
 
-def _prep(src, index, dim, dim_size):
+def _check_scatter(src, index, out, name):
+    if out is not None:
+        raise NotImplementedError(f"mtmc_mpn.{name}: `out=` is not supported")
     if not (src.is_cuda and index.is_cuda):
         raise RuntimeError("mtmc_mpn.scatter_*: tensors must be on a ROCm GPU (no CPU path)")
-    if dim not in (0, -src.dim()):
-        raise NotImplementedError("mtmc_mpn.scatter_*: only dim=0 (the reference's call form) is implemented")
-    if index.dim() != 1 or index.shape[0] != src.shape[0]:
-        raise RuntimeError("mtmc_mpn.scatter_*: index must be 1-D with one entry per row of src")
-    if dim_size is None:
-        dim_size = int(index.max()) + 1 if index.numel() else 0
-    src2 = src.reshape(src.shape[0], -1).contiguous().float()
-    return src2, index.contiguous().long(), int(dim_size)
 
 
 def scatter_add(src, index, dim=0, out=None, dim_size=None):
-    if out is not None:
-        raise NotImplementedError("mtmc_mpn.scatter_add: `out=` is not supported")
-    s2, idx, n = _prep(src, index, dim, dim_size)
-    res = torch.empty((n, s2.shape[1]), dtype=torch.float32, device=src.device)
-    with torch.cuda.device(src.device):
-        _lib.check(_lib.load().mtmc_scatter_add(s2.data_ptr(), idx.data_ptr(), s2.shape[0], s2.shape[1], n,
-                                                res.data_ptr(), _stream(src.device)))
-    return res.reshape((n,) + tuple(src.shape[1:]))
+    """`torch_scatter.scatter_add(src, index, dim=0, dim_size=N)`; integer `src` (the 1-D int64 form of reference
+    utils.py:173-174) is summed exactly and keeps its dtype."""
+    _check_scatter(src, index, out, "scatter_add")
+    return torch.ops.mtmc_mpn.scatter_add(src, index, dim, dim_size)
 
 
 scatter_sum = scatter_add
 
 
 def scatter_mean(src, index, dim=0, out=None, dim_size=None):
-    if out is not None:
-        raise NotImplementedError("mtmc_mpn.scatter_mean: `out=` is not supported")
-    s2, idx, n = _prep(src, index, dim, dim_size)
-    res = torch.empty((n, s2.shape[1]), dtype=torch.float32, device=src.device)
-    cnt = torch.empty((max(n, 1),), dtype=torch.float32, device=src.device)
-    with torch.cuda.device(src.device):
-        _lib.check(_lib.load().mtmc_scatter_mean(s2.data_ptr(), idx.data_ptr(), s2.shape[0], s2.shape[1], n,
-                                                 res.data_ptr(), cnt.data_ptr(), _stream(src.device)))
-    return res.reshape((n,) + tuple(src.shape[1:]))
+    _check_scatter(src, index, out, "scatter_mean")
+    return torch.ops.mtmc_mpn.scatter_mean(src, index, dim, dim_size)
 
 
 def scatter_max(src, index, dim=0, out=None, dim_size=None):
     """Returns (values, argmax) like torch_scatter; rows nobody writes hold 0 and argmax = src.size(0)."""
-    if out is not None:
-        raise NotImplementedError("mtmc_mpn.scatter_max: `out=` is not supported")
-    s2, idx, n = _prep(src, index, dim, dim_size)
-    res = torch.empty((n, s2.shape[1]), dtype=torch.float32, device=src.device)
-    arg = torch.empty((n, s2.shape[1]), dtype=torch.int64, device=src.device)
-    with torch.cuda.device(src.device):
-        _lib.check(_lib.load().mtmc_scatter_max(s2.data_ptr(), idx.data_ptr(), s2.shape[0], s2.shape[1], n,
-                                                res.data_ptr(), arg.data_ptr(), _stream(src.device)))
-    shape = (n,) + tuple(src.shape[1:])
-    return res.reshape(shape), arg.reshape(shape)
+    _check_scatter(src, index, out, "scatter_max")
+    return torch.ops.mtmc_mpn.scatter_max(src, index, dim, dim_size)
+
+
+def layer_forward(a: torch.Tensor, weight, bias, gamma=None, beta=None) -> torch.Tensor:
+    """One Linear (+ BatchNorm1d with batch statistics + ReLU when gamma/beta are given) on the GPU."""
+    if gamma is not None and a.shape[0] < 2:
+        raise ValueError("Expected more than 1 value per channel when training, got input size {}".format(list(a.shape)))
+    a = a.float()
+    if a.stride(-1) != 1:
+        a = a.contiguous()
+    out_dim, in_dim = weight.shape
+    lay = _lib.Layer()
+    lay.weight, lay.bias = weight.data_ptr(), bias.data_ptr()
+    lay.gamma = gamma.data_ptr() if gamma is not None else None
+    lay.beta = beta.data_ptr() if beta is not None else None
+    lay.in_dim, lay.out_dim = in_dim, out_dim
+    y = torch.empty((a.shape[0], out_dim), dtype=torch.float32, device=a.device)
+    stats = torch.empty((2 * out_dim,), dtype=torch.float64, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().mtmc_mlp_layer_forward(C.byref(lay), a.data_ptr(), a.stride(0), a.shape[0], y.data_ptr(),
+                                                      stats.data_ptr(), _stream(a.device)))
+    return y
 
 
 def mlp_forward(mlp, inp: torch.Tensor) -> torch.Tensor:
@@ -84,29 +81,14 @@ def mlp_forward(mlp, inp: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError("mtmc_mpn.MLP: training-mode Dropout is not built yet; use .eval()")
     if torch.is_grad_enabled() and (inp.requires_grad or any(p.requires_grad for p in mlp.parameters())):
         raise NotImplementedError("mtmc_mpn.MLP: backward is not built yet; call under torch.no_grad()")
-    lib = _lib.load()
-    a = inp.float()
-    if a.stride(-1) != 1:
-        a = a.contiguous()
-    with torch.cuda.device(inp.device):
-        for spec in mlp.layers:
-            lin = mlp.fc_layers[spec.lin_slot]
-            bn = mlp.fc_layers[spec.bn_slot] if spec.bn_slot is not None else None
-            lay = _lib.Layer()
-            lay.weight, lay.bias = lin.weight.data_ptr(), lin.bias.data_ptr()
-            lay.gamma = bn.weight.data_ptr() if bn is not None else None
-            lay.beta = bn.bias.data_ptr() if bn is not None else None
-            lay.in_dim, lay.out_dim = spec.in_dim, spec.out_dim
-            if bn is not None and a.shape[0] < 2:
-                raise ValueError("Expected more than 1 value per channel when training, got input size {}".format(
-                    list(a.shape)))
-            y = torch.empty((a.shape[0], spec.out_dim), dtype=torch.float32, device=inp.device)
-            stats = torch.empty((2 * spec.out_dim,), dtype=torch.float64, device=inp.device)
-            _lib.check(lib.mtmc_mlp_layer_forward(C.byref(lay), a.data_ptr(), a.stride(0), a.shape[0], y.data_ptr(),
-                                                  stats.data_ptr(), _stream(inp.device)))
-            if spec.relu and bn is None:
-                y = torch.relu_(y)
-            a = y
+    a = inp
+    for spec in mlp.layers:
+        lin = mlp.fc_layers[spec.lin_slot]
+        bn = mlp.fc_layers[spec.bn_slot] if spec.bn_slot is not None else None
+        a = layer_forward(a, lin.weight, lin.bias, bn.weight if bn is not None else None,
+                          bn.bias if bn is not None else None)
+        if spec.relu and bn is None:
+            a = torch.relu_(a)
     return a
 
 

@@ -1,0 +1,294 @@
+"""PyTorch-ROCm custom-op registration of the hot path: `torch.ops.mtmc_mpn.*`.
+
+BASELINE.json's north_star asks for the MPN forward "registered as a PyTorch-ROCm custom op so main.py / train.py /
+inference.py call an unchanged MPN nn.Module signature"; SURVEY.md 8(b) names the namespace.  The ops below are thin
+schemas over the C ABI of include/mtmc_mpn.h (one library call each, on the current HIP stream) -- there is no second
+implementation behind them: `MOTMPNet.forward` itself dispatches through `torch.ops.mtmc_mpn.mp_forward`, autograd
+through `torch.ops.mtmc_mpn.mp_backward`.  CUDA (= ROCm) dispatch key only: CPU tensors have no kernel and raise.
+
+  mp_forward(x, edge_index, edge_attr, params, config, training, seed, flags, tape) -> (logits[S,E,C], h[N,32], tape)
+      the whole `MOTMPNet.forward` (reference models/mpn.py:250-299).  `params`: the 34 tensors in struct order
+      (`engine.layer_slots`: node encoder, edge encoder, edge update, node update, classifier; weight, bias, gamma, beta),
+      `config`: JSON of {"params": GRAPH_NET_PARAMS, "arch": ...}.  `tape=True` keeps every round's buffers in the third
+      output for `mp_backward` (training / grad mode); otherwise it is empty.
+  mp_backward(tape, x, edge_index, edge_attr, params, config, training, seed, flags, d_logits, d_h, need_x, need_attr)
+      -> (flat parameter gradients, d_x, d_edge_attr)         (reference train.py:424, loss.backward())
+  encode_nodes(x, params, config) -> h0[N,32]                 the node encoder alone (models/mpn.py:131, eval mode)
+  scatter_add / scatter_mean / scatter_max(src, index, dim, dim_size)   the torch_scatter call forms
+      (models/mpn.py:196-202; the 1-D int64 form of utils.py:173-174 returns int64)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+from typing import List, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from . import config as _config
+
+CHECK_INDICES = 1 << 16          # host-side flag bit of `flags`: synchronise and raise IndexError on bad edge_index
+_ENGINES = {}
+
+
+def config_key(model_params, arch) -> str:
+    return json.dumps({"params": model_params, "arch": arch}, sort_keys=True, default=str)
+
+
+def engine_for(config: str):
+    eng = _ENGINES.get(config)
+    if eng is None:
+        cfg = json.loads(config)
+        spec = _config.resolve(cfg["params"], cfg["arch"])
+        ok, why = _config.check_supported(spec)
+        if not ok:
+            raise NotImplementedError("mtmc_mpn HIP path does not cover this GRAPH_NET_PARAMS: " + why)
+        from .engine import ForwardEngine
+        eng = _ENGINES[config] = ForwardEngine(spec)
+    return eng
+
+
+def grad_layout(spec):
+    """(offset, numel, shape) of every parameter gradient inside the flat buffer mp_backward returns (256-byte pieces)."""
+    from .engine import layer_slots
+    out, total = [], 0
+    for _, _, layer in layer_slots(spec):
+        shapes = [(layer.out_dim, layer.in_dim), (layer.out_dim,)]
+        if layer.bn_slot is not None:
+            shapes += [(layer.out_dim,), (layer.out_dim,)]
+        for shp in shapes:
+            n = 1
+            for d in shp:
+                n *= d
+            out.append((total, n, shp))
+            total += (n + 63) // 64 * 64
+    return out, total
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# schemas
+# ---------------------------------------------------------------------------------------------------------------
+torch.library.define(
+    "mtmc_mpn::mp_forward",
+    "(Tensor x, Tensor edge_index, Tensor edge_attr, Tensor[] params, str config, bool training, int seed, int flags, "
+    "bool tape) -> (Tensor, Tensor, Tensor)")
+torch.library.define(
+    "mtmc_mpn::mp_backward",
+    "(Tensor tape, Tensor x, Tensor edge_index, Tensor edge_attr, Tensor[] params, str config, bool training, int seed, "
+    "int flags, Tensor? d_logits, Tensor? d_h, bool need_x, bool need_attr) -> (Tensor, Tensor, Tensor)")
+torch.library.define("mtmc_mpn::encode_nodes", "(Tensor x, Tensor[] params, str config) -> Tensor")
+torch.library.define("mtmc_mpn::scatter_add", "(Tensor src, Tensor index, int dim, int? dim_size) -> Tensor")
+torch.library.define("mtmc_mpn::scatter_mean", "(Tensor src, Tensor index, int dim, int? dim_size) -> Tensor")
+torch.library.define("mtmc_mpn::scatter_max", "(Tensor src, Tensor index, int dim, int? dim_size) -> (Tensor, Tensor)")
+
+
+def _n_out(spec):
+    return min(spec.num_class_steps, spec.num_enc_steps) if spec.num_enc_steps > 0 else 1
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the forward
+# ---------------------------------------------------------------------------------------------------------------
+@torch.library.impl("mtmc_mpn::mp_forward", "CUDA")
+def _mp_forward(x, edge_index, edge_attr, params, config, training, seed, flags, tape):
+    eng = engine_for(config)
+    eng.flags = int(flags) & 0xFFFF
+    prep = eng.prepare(x, edge_index, edge_attr, tape=bool(tape), seed=seed, params=list(params))
+    if tape and not training:                  # eval-mode statistics / identity Dropout, but still differentiable
+        prep.model.dropout_enc = prep.model.dropout_upd_edge = prep.model.dropout_upd_node = 0.0
+    with torch.cuda.device(prep.dev):
+        _lib.check(eng.lib.mtmc_mpn_forward(C.byref(prep.model), C.byref(prep.call)))
+        if flags & CHECK_INDICES:
+            lay = eng.layout(prep)
+            bits = prep.ws[lay.flags_off:lay.flags_off + 32].view(torch.int32).cpu()
+            if int(bits[1]) != 0:
+                raise IndexError("mtmc_mpn: edge_index holds node ids outside [0, N)")
+    return prep.logits, prep.h, (prep.ws if tape else prep.ws.new_empty(0))
+
+
+@torch.library.register_fake("mtmc_mpn::mp_forward")
+def _mp_forward_fake(x, edge_index, edge_attr, params, config, training, seed, flags, tape):
+    spec = engine_for(config).spec
+    e = edge_index.shape[1]
+    return (x.new_empty((_n_out(spec), e, spec.cls_edge[0].out_dim)), x.new_empty((x.shape[0], spec.node_dim)),
+            x.new_empty((0,), dtype=torch.uint8))
+
+
+@torch.library.impl("mtmc_mpn::mp_backward", "CUDA")
+def _mp_backward(tape, x, edge_index, edge_attr, params, config, training, seed, flags, d_logits, d_h, need_x, need_attr):
+    eng = engine_for(config)
+    eng.flags = int(flags) & 0xFFFF
+    spec = eng.spec
+    prep = eng.prepare(x, edge_index, edge_attr, tape=True, seed=seed, params=list(params), tape_ws=tape)
+    if not training:
+        prep.model.dropout_enc = prep.model.dropout_upd_edge = prep.model.dropout_upd_node = 0.0
+    dev = prep.dev
+    layout, total = grad_layout(spec)
+    flat = torch.empty(total, dtype=torch.float32, device=dev)
+    base = flat.data_ptr()
+    grads = _lib.Model()
+    it = iter(layout)
+    from .engine import layer_slots
+    for slot, idx, layer in layer_slots(spec):
+        dst = getattr(grads, slot) if idx is None else getattr(grads, slot)[idx]
+        dst.weight, dst.bias = base + 4 * next(it)[0], base + 4 * next(it)[0]
+        if layer.bn_slot is not None:
+            dst.gamma, dst.beta = base + 4 * next(it)[0], base + 4 * next(it)[0]
+        dst.in_dim, dst.out_dim = layer.in_dim, layer.out_dim
+    dx = torch.empty((prep.n, spec.enc_node[0].in_dim), device=dev) if need_x else flat.new_empty(0)
+    dattr = torch.empty((prep.e, spec.enc_edge[0].in_dim), device=dev) if need_attr else flat.new_empty(0)
+    dl = d_logits.contiguous().float() if d_logits is not None else None
+    dh = d_h.contiguous().float() if d_h is not None else None
+    n_steps = _n_out(spec)
+    step_bytes = 4 * prep.e * spec.cls_edge[0].out_dim
+    steps = (C.c_void_p * max(n_steps, 1))(*[(dl.data_ptr() + i * step_bytes) if dl is not None and dl.numel() else None
+                                             for i in range(n_steps)])
+    with torch.cuda.device(dev):
+        prep.call.stream = _stream(dev)
+        _lib.check(eng.lib.mtmc_mpn_backward_steps(
+            C.byref(prep.model), C.byref(prep.call), steps, dh.data_ptr() if dh is not None else None,
+            C.byref(grads), flat.data_ptr(), flat.numel() * 4,
+            dx.data_ptr() if need_x else None, dattr.data_ptr() if need_attr else None))
+    return flat, dx, dattr
+
+
+@torch.library.register_fake("mtmc_mpn::mp_backward")
+def _mp_backward_fake(tape, x, edge_index, edge_attr, params, config, training, seed, flags, d_logits, d_h, need_x, need_attr):
+    _, total = grad_layout(engine_for(config).spec)
+    return (x.new_empty((total,)), x.new_empty(x.shape if need_x else (0,)),
+            edge_attr.new_empty(edge_attr.shape if need_attr else (0,)))
+
+
+def _setup_context(ctx, inputs, output):
+    x, edge_index, edge_attr, params, config, training, seed, flags, tape = inputs
+    ctx.config, ctx.training, ctx.seed, ctx.flags, ctx.n_params = config, training, seed, flags, len(params)
+    ctx.need_x, ctx.need_attr = x.requires_grad, edge_attr.requires_grad
+    ctx.has_tape = bool(tape)
+    ctx.save_for_backward(output[2], x, edge_index, edge_attr, *params)
+
+
+def _autograd_backward(ctx, d_logits, d_h, _d_tape):
+    if not ctx.has_tape:
+        raise RuntimeError("mtmc_mpn: mp_forward was called with tape=False; nothing to differentiate through")
+    tape, x, edge_index, edge_attr, *params = ctx.saved_tensors
+    flat, dx, dattr = torch.ops.mtmc_mpn.mp_backward(tape, x, edge_index, edge_attr, params, ctx.config, ctx.training,
+                                                      ctx.seed, ctx.flags, d_logits, d_h, ctx.need_x, ctx.need_attr)
+    spec = engine_for(ctx.config).spec
+    layout, _ = grad_layout(spec)
+    grads = [flat[o:o + n].view(shp) for o, n, shp in layout]
+    if spec.num_enc_steps == 0:               # the update MLPs took no part: None, as autograd gives the reference
+        from .engine import layer_slots
+        i = 0
+        for slot, _, layer in layer_slots(spec):
+            k = 4 if layer.bn_slot is not None else 2
+            if slot in ("upd_edge", "upd_node"):
+                grads[i:i + k] = [None] * k
+            i += k
+    return (dx if ctx.need_x else None, None, dattr if ctx.need_attr else None, grads, None, None, None, None, None)
+
+
+torch.library.register_autograd("mtmc_mpn::mp_forward", _autograd_backward, setup_context=_setup_context)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the node encoder alone, and the torch_scatter call forms
+# ---------------------------------------------------------------------------------------------------------------
+@torch.library.impl("mtmc_mpn::encode_nodes", "CUDA")
+def _encode_nodes(x, params, config):
+    from . import ops
+    eng = engine_for(config)
+    layers = eng.spec.enc_node
+    if x.dim() != 2 or x.shape[1] != layers[0].in_dim or len(params) != 4 * len(layers):
+        raise RuntimeError("mtmc_mpn.encode_nodes: x must be [N, in_dim] and params the 4 tensors of every encoder layer")
+    a = x
+    for i, layer in enumerate(layers):
+        w, b, g, beta = params[4 * i:4 * i + 4]
+        a = ops.layer_forward(a, w, b, g, beta)
+    return a
+
+
+@torch.library.register_fake("mtmc_mpn::encode_nodes")
+def _encode_nodes_fake(x, params, config):
+    return x.new_empty((x.shape[0], engine_for(config).spec.node_dim))
+
+
+def _scatter_args(src, index, dim, dim_size):
+    if dim not in (0, -src.dim()):
+        raise NotImplementedError("mtmc_mpn.scatter_*: only dim=0 (the reference's call form) is implemented")
+    if index.dim() != 1 or index.shape[0] != src.shape[0]:
+        raise RuntimeError("mtmc_mpn.scatter_*: index must be 1-D with one entry per row of src")
+    if dim_size is None:
+        dim_size = int(index.max()) + 1 if index.numel() else 0
+    return src.reshape(src.shape[0], -1).contiguous(), index.contiguous().long(), int(dim_size)
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+@torch.library.impl("mtmc_mpn::scatter_add", "CUDA")
+def _scatter_add(src, index, dim, dim_size):
+    s2, idx, n = _scatter_args(src, index, dim, dim_size)
+    lib = _lib.load()
+    with torch.cuda.device(src.device):
+        if not src.dtype.is_floating_point:        # utils.py:173-174: int64 in, int64 out
+            s2 = s2.long()
+            res = torch.empty((n, s2.shape[1]), dtype=torch.int64, device=src.device)
+            _lib.check(lib.mtmc_scatter_add_i64(s2.data_ptr(), idx.data_ptr(), s2.shape[0], s2.shape[1], n,
+                                                res.data_ptr(), _stream(src.device)))
+            return res.reshape((n,) + tuple(src.shape[1:])).to(src.dtype)
+        s2 = s2.float()
+        res = torch.empty((n, s2.shape[1]), dtype=torch.float32, device=src.device)
+        _lib.check(lib.mtmc_scatter_add(s2.data_ptr(), idx.data_ptr(), s2.shape[0], s2.shape[1], n, res.data_ptr(),
+                                        _stream(src.device)))
+    return res.reshape((n,) + tuple(src.shape[1:]))
+
+
+@torch.library.impl("mtmc_mpn::scatter_mean", "CUDA")
+def _scatter_mean(src, index, dim, dim_size):
+    s2, idx, n = _scatter_args(src, index, dim, dim_size)
+    s2 = s2.float()
+    res = torch.empty((n, s2.shape[1]), dtype=torch.float32, device=src.device)
+    cnt = torch.empty((max(n, 1),), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        _lib.check(_lib.load().mtmc_scatter_mean(s2.data_ptr(), idx.data_ptr(), s2.shape[0], s2.shape[1], n,
+                                                 res.data_ptr(), cnt.data_ptr(), _stream(src.device)))
+    return res.reshape((n,) + tuple(src.shape[1:]))
+
+
+@torch.library.impl("mtmc_mpn::scatter_max", "CUDA")
+def _scatter_max(src, index, dim, dim_size):
+    s2, idx, n = _scatter_args(src, index, dim, dim_size)
+    s2 = s2.float()
+    res = torch.empty((n, s2.shape[1]), dtype=torch.float32, device=src.device)
+    arg = torch.empty((n, s2.shape[1]), dtype=torch.int64, device=src.device)
+    with torch.cuda.device(src.device):
+        _lib.check(_lib.load().mtmc_scatter_max(s2.data_ptr(), idx.data_ptr(), s2.shape[0], s2.shape[1], n,
+                                                res.data_ptr(), arg.data_ptr(), _stream(src.device)))
+    shape = (n,) + tuple(src.shape[1:])
+    return res.reshape(shape), arg.reshape(shape)
+
+
+def _scatter_fake_shape(src, index, dim_size):
+    if dim_size is None:
+        raise RuntimeError("mtmc_mpn.scatter_*: dim_size is needed to trace the op")
+    return (int(dim_size),) + tuple(src.shape[1:])
+
+
+@torch.library.register_fake("mtmc_mpn::scatter_add")
+def _scatter_add_fake(src, index, dim, dim_size):
+    return src.new_empty(_scatter_fake_shape(src, index, dim_size),
+                         dtype=src.dtype if not src.dtype.is_floating_point else torch.float32)
+
+
+@torch.library.register_fake("mtmc_mpn::scatter_mean")
+def _scatter_mean_fake(src, index, dim, dim_size):
+    return src.new_empty(_scatter_fake_shape(src, index, dim_size), dtype=torch.float32)
+
+
+@torch.library.register_fake("mtmc_mpn::scatter_max")
+def _scatter_max_fake(src, index, dim, dim_size):
+    shp = _scatter_fake_shape(src, index, dim_size)
+    return src.new_empty(shp, dtype=torch.float32), src.new_empty(shp, dtype=torch.int64)

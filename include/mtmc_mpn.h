@@ -190,6 +190,10 @@ int32_t mtmc_mpn_run_phase(const mtmc_mpn_model* model, const mtmc_mpn_call* cal
  * mean divides by max(count,1); max also writes arg_out[dim_size, C] (int64, E where untouched) if non-NULL. */
 int32_t mtmc_scatter_add(const float* src, const int64_t* index, int64_t n_src, int64_t n_cols,
                          int64_t dim_size, float* out, void* stream);
+/* the integer call form of the reference's post-processing, scatter_add(int64 [E], index, dim_size=N)
+ * (reference utils.py:173-174, :308-309): int64 in, int64 out, exact */
+int32_t mtmc_scatter_add_i64(const int64_t* src, const int64_t* index, int64_t n_src, int64_t n_cols,
+                             int64_t dim_size, int64_t* out, void* stream);
 int32_t mtmc_scatter_mean(const float* src, const int64_t* index, int64_t n_src, int64_t n_cols,
                           int64_t dim_size, float* out, float* count_scratch, void* stream);
 int32_t mtmc_scatter_max(const float* src, const int64_t* index, int64_t n_src, int64_t n_cols,
@@ -237,7 +241,6 @@ int32_t mtmc_build_graph(const float* feats, int64_t feat_row_stride, int64_t n_
  * sums[0] (NULL to skip).  Rows with y_i == ignore_index count for nothing.
  * backward: d_logits[i][c] = g_i * w[y_i] * (softmax(x_i)[c] - [c == y_i]) with g_i = grad[0]/sums[1] (mean, needs the
  * forward's sums), grad[0] (sum) or grad[i] (none).  All pointers are device pointers. */
-#define MTMC_STAT_REPLICAS 16
 int32_t mtmc_cross_entropy_forward(const float* logits, const int64_t* labels, const float* weight, int64_t n,
                                    int32_t n_classes, int64_t ignore_index, int32_t mode, float* per_sample,
                                    double* sums, float* loss_out, void* stream);

@@ -1,0 +1,64 @@
+"""`torch.ops.mtmc_mpn.*` (north_star: "registered as a PyTorch-ROCm custom op"): schemas exist, shape
+inference works without a GPU, and there is no CPU kernel behind them (CPU tensors raise instead of computing)."""
+import copy
+
+import pytest
+import torch
+
+import mtmc_mpn
+from mtmc_mpn import engine, torch_ops
+
+ARCH = "resnet101"
+OPS = ["mp_forward", "mp_backward", "encode_nodes", "scatter_add", "scatter_mean", "scatter_max"]
+
+
+def _model(L=3, Cs=2):
+    params = mtmc_mpn.default_params(num_enc_steps=L, num_class_steps=Cs)
+    m = mtmc_mpn.MOTMPNet(copy.deepcopy(params), None, ARCH).eval()
+    return m, torch_ops.config_key(m.model_params, m.arch)
+
+
+def test_ops_are_registered_with_schemas():
+    for name in OPS:
+        op = getattr(torch.ops.mtmc_mpn, name)
+        assert "mtmc_mpn::" + name in str(op.default._schema)
+    assert "Tensor[] params" in str(torch.ops.mtmc_mpn.mp_forward.default._schema)
+
+
+def test_no_cpu_kernel_behind_the_ops():
+    m, key = _model()
+    x, ei, ea = torch.randn(8, 2048), torch.randint(0, 8, (2, 20)), torch.rand(20, 2)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.mtmc_mpn.mp_forward(x, ei, ea, engine.ordered_params(m), key, False, 0, 0, False)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.mtmc_mpn.scatter_add(torch.ones(5, dtype=torch.int64), torch.zeros(5, dtype=torch.int64), 0, 3)
+    with pytest.raises(RuntimeError):
+        m(__import__("types").SimpleNamespace(x=x, edge_index=ei, edge_attr=ea))
+
+
+def test_shape_inference_under_fake_tensors():
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    m, key = _model(L=3, Cs=2)
+    params = engine.ordered_params(m)
+    assert len(params) == 34
+    with FakeTensorMode(allow_non_fake_inputs=True) as mode:
+        x, ei, ea = torch.empty(50, 2048), torch.empty(2, 700, dtype=torch.int64), torch.empty(700, 2)
+        fp = [mode.from_tensor(p.detach()) for p in params]
+        logits, h, tape = torch.ops.mtmc_mpn.mp_forward(x, ei, ea, fp, key, False, 0, 0, False)
+        assert logits.shape == (2, 700, 2) and h.shape == (50, 32) and tape.numel() == 0
+        flat, dx, dattr = torch.ops.mtmc_mpn.mp_backward(tape, x, ei, ea, fp, key, True, 1, 0, logits, None, True, False)
+        assert flat.numel() >= sum(p.numel() for p in params) and dx.shape == x.shape and dattr.numel() == 0
+        assert torch.ops.mtmc_mpn.encode_nodes(x, fp[:16], key).shape == (50, 32)
+        out = torch.ops.mtmc_mpn.scatter_add(torch.empty(700, dtype=torch.int64), ei[0], 0, 50)
+        assert out.shape == (50,) and out.dtype == torch.int64
+        v, a = torch.ops.mtmc_mpn.scatter_max(torch.empty(700, 32), ei[0], 0, 50)
+        assert v.shape == (50, 32) and a.dtype == torch.int64
+
+
+def test_gradient_layout_covers_every_parameter_once():
+    m, key = _model()
+    layout, total = torch_ops.grad_layout(m.spec)
+    params = engine.ordered_params(m)
+    assert [tuple(p.shape) for p in params] == [shp for _, _, shp in layout]
+    ends = [o + n for o, n, _ in layout]
+    assert all(o % 64 == 0 for o, _, _ in layout) and all(e <= s for e, (s, _, _) in zip(ends, layout[1:])) and ends[-1] <= total
