@@ -8,9 +8,11 @@ and calling the MPN (reference inference.py:402-458, identically train.py:316-34
     edge_label = 1.0 where both ends carry the same identity                     inference.py:446-450
     edge_attr  = [pairwise_distance(x[r], x[c]), 1 - cosine_similarity(x[r], x[c])]   inference.py:453-456
 
-Parity status: those reference lines live inside long functions that need torch_geometric / the dataset and cannot
-be imported here, so this restatement is pinned by construction (same torch functions, same arguments), not by
-reference-generated vectors.  Only tests/ may import it.
+Parity status: PINNED.  tests/golden/make_golden_graph.py drives the reference's own
+`inference.inference_precomputed_features` (inference.py:372-458, imported unmodified) with a stub loader and a stub MPN
+that captures the `Data` object, asserts that `build()` below reproduces x / edge_index / edge_attr / edge_labels bit
+for bit, and stores the fixtures tests/golden/gb_*.npz that tests/test_graph_golden.py checks this file and the HIP
+builder against.  train.py:316-342 / :557-561 are the same statements on the same names.  Only tests/ may import it.
 """
 import numpy as np
 import torch
