@@ -69,16 +69,25 @@ def algorithmic_bytes_forward(n, e, L, cs, f=2048):
     return (f * 4 + 128) * n + 24 * e + L * (176 * e + 256 * n) + cs * 8 * e
 
 
+def pmc_round(workload):
+    """The newest round whose counter summaries for this workload are committed under profiles/."""
+    for rnd in ("r02", "r01"):
+        if all(os.path.exists(os.path.join(ROOT, "profiles", f"{rnd}_{workload}_pmc_{c}.txt")) for c in ("FETCH_SIZE", "WRITE_SIZE")):
+            return rnd
+    return None
+
+
 def pmc_traffic(workload, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summaries (profiles/r01_<workload>_pmc_*.txt,
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summaries (profiles/rNN_<workload>_pmc_*.txt,
     made by tools/pmc_summary.py from separate FETCH_SIZE and WRITE_SIZE passes of tools/fwd_loop.py on the same
     workload).  Units are KB; on gfx950 FETCH_SIZE counts wide (16 B/lane) streaming reads at one half
     (MI355X_MICROARCH.md, HBM), so reads are doubled; WRITE_SIZE is exact.  None when no summary is committed."""
     tot = {}
+    rnd = pmc_round(workload)
+    if rnd is None:
+        return None
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-        path = os.path.join(ROOT, "profiles", f"r01_{workload}_pmc_{ctr}.txt")
-        if not os.path.exists(path):
-            return None
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{workload}_pmc_{ctr}.txt")
         num = den = 0.0
         for line in open(path):
             parts = line.split()
@@ -126,23 +135,64 @@ def phase_cost(ph, arg, spec, n, e):
     return "hbm", float(table[ph])
 
 
-def time_forward(model, data, steps, warmup, dist=None):
+def percentiles(v):
+    v = sorted(v)
+    n = len(v)
+    return {"median": v[n // 2], "p10": v[int(0.1 * (n - 1))], "p90": v[int(round(0.9 * (n - 1)))], "min": v[0], "max": v[-1]}
+
+
+def time_forward(model, data, steps, warmup, dist=None, fn=None):
+    """W untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides (the driver's contract):
+    returns (seconds per step from the wall clock, per-step GPU milliseconds from HIP events recorded on the launch
+    stream between consecutive steps -> median / p10 / p90)."""
     dev = data.x.device
+    fn = fn or (lambda: model(data))
     with torch.no_grad():
         for _ in range(warmup):
-            model(data)
+            fn()
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         t0 = time.perf_counter()
-        for _ in range(steps):
-            model(data)
+        marks[0].record()
+        for i in range(steps):
+            fn()
+            marks[i + 1].record()
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
         t1 = time.perf_counter()
-    return (t1 - t0) / steps
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    return (t1 - t0) / steps, percentiles(per_step)
+
+
+def hbm_probe(device, gib=2, reps=20):
+    """Measured HBM bandwidth of THIS box ("confirm on the box ... report against the measured peak too"):
+    a device-to-device copy (read + write) and a triad a = b + s*c (two reads + one write) over buffers far larger
+    than the 256 MB Infinity Cache; best of `reps`, HIP events."""
+    n = gib * (1 << 30) // 4
+    a, b, c = (torch.empty(n, dtype=torch.float32, device=device) for _ in range(3))
+    b.fill_(1.0), c.fill_(2.0)
+    out = {}
+    for name, fn, nbytes in (("copy", lambda: a.copy_(b), 2 * 4 * n), ("triad", lambda: torch.add(b, c, alpha=0.5, out=a), 3 * 4 * n)):
+        best = 1e30
+        for _ in range(3):
+            fn()
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        out[name + "_GBps"] = nbytes / (best * 1e-3) / 1e9
+    out["buffer_GiB"] = gib
+    out["measured_peak_GBps"] = max(out["copy_GBps"], out["triad_GBps"])
+    del a, b, c
+    torch.cuda.empty_cache()
+    return out
 
 
 def time_phases(model, data, iters):
@@ -233,23 +283,17 @@ def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
     model.deterministic = bool(os.environ.get("MTMC_DETERMINISTIC"))
     data = make_workload(name, device)
     n, e = data.x.shape[0], data.edge_index.shape[1]
-    sec = time_forward(model, data, steps, warmup)
+    sec, dist_ms = time_forward(model, data, steps, warmup)
     launch_mode, eager_ms, replay_ms = "eager launches", sec * 1e3, None
     if e <= 2_000_000 and not os.environ.get("MTMC_NO_GRAPH"):
         # few-edge graphs: ~25 launches per forward can cost the host more than the forward costs the GPU; the same
         # forward replayed from a HIP graph (model.capture) is immune to that -- report the faster way of launching it
         with torch.no_grad():
             replay = model.capture(data)
-            for _ in range(warmup):
-                replay()
-            torch.cuda.synchronize(device)
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                replay()
-            torch.cuda.synchronize(device)
-            replay_ms = (time.perf_counter() - t0) / steps * 1e3
+        r_sec, r_dist = time_forward(model, data, steps, warmup, fn=replay)
+        replay_ms = r_sec * 1e3
         if replay_ms < eager_ms:
-            sec, launch_mode = replay_ms * 1e-3, "HIP graph replay (model.capture)"
+            sec, dist_ms, launch_mode = r_sec, r_dist, "HIP graph replay (model.capture)"
     seq, ms = time_phases(model, data, phase_iters)
     spec = model.spec
     # dominant kernel = the kernel NAME with the largest summed time (all its launches in a step, the same
@@ -287,8 +331,9 @@ def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
         roofline["peak_note"] = peak_note
     roofline["traffic"] = pmc_traffic(name, dom_key)
     if roofline["traffic"] is not None:
-        roofline["traffic_note"] = ("HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01_%s_pmc_*.txt "
-                                    "(separate rocprofv3 --pmc passes; gfx950 half-count correction on reads)" % name)
+        roofline["traffic_note"] = ("HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/%s_%s_pmc_*.txt "
+                                    "(separate rocprofv3 --pmc passes; gfx950 half-count correction on reads)"
+                                    % (pmc_round(name), name))
     b_fwd = algorithmic_bytes_forward(n, e, L, cs)
     phases = {}
     for (ph, arg), t in zip(seq, ms):
@@ -297,6 +342,7 @@ def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
     res = {"workload": name, "description": desc, "N": n, "E": e, "L": L, "Cs": cs,
            "value": e / sec, "ms_per_step": sec * 1e3, "edge_rounds_per_s": e * L / sec,
            "launch": {"mode": launch_mode, "eager_ms": eager_ms, "graph_replay_ms": replay_ms},
+           "step_ms": {k: round(v, 5) for k, v in dist_ms.items()},
            "roofline": roofline,
            "forward_algorithmic": {"bytes": b_fwd, "GBps": b_fwd / sec / 1e9, "frac_of_hbm_peak": b_fwd / sec / 1e9 / HBM_PEAK_GBS,
                                    "note": "SURVEY 8(d) reference-formulation bytes / whole-forward time"},
@@ -340,7 +386,8 @@ def run_graph_build(device, with_cpu=True):
 
 def run_postprocess(device, with_cpu=True):
     """last logits -> (predictions, ID_pred), S02-scale scenario (the pp8 fixture's recipe)."""
-    from mtmc_mpn import pp_cases
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pp_cases          # seeded post-processing scenarios (test infrastructure, shared with the fixtures)
     kw = dict(n_ids=140, n_cams=4, seed=20, fp_rate=0.0005, fn_rate=0.05, pair_fp=0.0006)
     sc = pp_cases.scenario(**kw)
     logits, ei = sc.logits.to(device), sc.edge_index.to(device)
@@ -406,19 +453,58 @@ def run_training_step(device):
         loss.backward()
         opt.step()
         return loss
-    for _ in range(5):
+    import gc
+    gc.collect()
+    for _ in range(20):
         step()
     torch.cuda.synchronize(device)
+    reps = 60
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    host = []
     t0 = time.perf_counter()
-    reps = 30
-    for _ in range(reps):
+    marks[0].record()
+    for i in range(reps):
+        h0 = time.perf_counter()
         loss = step()
+        host.append((time.perf_counter() - h0) * 1e3)
+        marks[i + 1].record()
     torch.cuda.synchronize(device)
     sec = (time.perf_counter() - t0) / reps
+    gpu = [marks[i].elapsed_time(marks[i + 1]) for i in range(reps)]
     e = data.edge_index.shape[1]
-    return {"workload": "training-scene topology, 100 identities: forward(Dropout) + class-weighted CE (the shipped loss) + backward + SGD, L=3 Cs=3",
-            "N": int(data.x.shape[0]), "E": int(e), "ms_per_step": sec * 1e3, "edges_per_s": e / sec,
-            "final_loss": float(loss.detach())}
+    out = {"workload": "training-scene topology, 100 identities: forward(Dropout) + class-weighted CE (the shipped loss) + backward + SGD, L=3 Cs=3",
+           "N": int(data.x.shape[0]), "E": int(e), "ms_per_step": sec * 1e3, "edges_per_s": e / sec,
+           "step_ms_gpu_side": {k: round(v, 4) for k, v in percentiles(gpu).items()},
+           "step_ms_host_issue": {k: round(v, 4) for k, v in percentiles(host).items()},
+           "final_loss": float(loss.detach())}
+    kt = train_kernel_ms()
+    if kt is not None:
+        out["kernel_ms_per_step"] = kt
+        out["kernel_note"] = ("sum of kernel durations per step from the committed rocprofv3 --kernel-trace --stats summary "
+                              "(profiles/%s): what the GPU needs; the rest of ms_per_step is host launch time" % kt["source"])
+    return out
+
+
+def train_kernel_ms():
+    """Kernel time of one training step from the newest committed rocprofv3 summary (tools/train_profile.sh)."""
+    import csv
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_train_kernel_stats.csv")
+        meta = os.path.join(ROOT, "profiles", f"{rnd}_train_kernel_stats.steps")
+        if os.path.exists(path):
+            steps = int(open(meta).read().split()[0]) if os.path.exists(meta) else None
+            total_ns = sum(float(r["TotalDurationNs"]) for r in csv.DictReader(open(path)) if r.get("TotalDurationNs"))
+            if steps:
+                return {"ms": total_ns / steps * 1e-6, "source": os.path.basename(path), "profiled_steps": steps}
+    return None
+
+
+def add_measured_peak(res, probe):
+    """Fractions against the bandwidth this box actually delivers (hbm_probe), beside the ones against the 8 TB/s spec."""
+    peak = probe["measured_peak_GBps"]
+    res["forward_algorithmic"]["frac_of_measured_peak"] = res["forward_algorithmic"]["GBps"] / peak
+    if res["roofline"]["bound"] == "hbm":
+        res["roofline"]["frac_of_measured_peak"] = res["roofline"]["achieved"] / peak
 
 
 def main():
@@ -439,7 +525,9 @@ def main():
     device = torch.device("cuda:0")
     torch.cuda.set_device(device)
     name = "s02" if args.workload == "auto" else args.workload
+    probe = hbm_probe(device)
     res = run_single(name, device, args.steps, args.warmup, with_cpu=not args.no_cpu)
+    add_measured_peak(res, probe)
     line = {"metric": "MPN forward edges/sec (+ achieved roofline fraction of the dominant kernel)",
             "value": res["value"], "unit": "edges/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -448,13 +536,15 @@ def main():
                        "N": res["N"], "E": res["E"], "parallelism": "1 GPU"},
             "roofline": res["roofline"], "cpu_baseline": res.get("cpu_baseline"), "launch": res["launch"],
             "forward_algorithmic": res["forward_algorithmic"], "edge_rounds_per_s": res["edge_rounds_per_s"],
-            "phase_ms": res["phase_ms"]}
+            "phase_ms": res["phase_ms"], "step_ms": res["step_ms"], "hbm_probe": probe}
     if args.workload == "auto" and not args.no_stress:
         st = run_single("cfg4", device, max(5, args.steps // 10), max(2, args.warmup // 10), with_cpu=not args.no_cpu,
                         phase_iters=5)
+        add_measured_peak(st, probe)
         line["stress"] = st
         # the multi-GPU workload (config 5) on this one GPU: the N=1 point of the strong-scaling curve
         line["scale_base"] = run_single("cfg5", device, 5, 2, with_cpu=False, phase_iters=2)
+        add_measured_peak(line["scale_base"], probe)
         line["scale_base"]["note"] = ("1-GPU point of the strong-scaling series that `--gpus N` (N > 1) reports: the same "
                                       "1M-node / 100M-edge graph, one call, no collectives")
         line["graph_build"] = run_graph_build(device, with_cpu=not args.no_cpu)

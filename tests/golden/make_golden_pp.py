@@ -30,7 +30,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import mtmc_mpn  # noqa: E402,F401
-from mtmc_mpn import pp_cases  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import pp_cases  # noqa: E402
 from oracle import postprocess_oracle as po  # noqa: E402
 import inference as ref_inference  # noqa: E402  (the reference, unmodified)
 import utils as ref_utils  # noqa: E402  (the reference, unmodified)

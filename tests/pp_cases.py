@@ -11,7 +11,7 @@ import types
 
 import torch
 
-from . import graphs
+from mtmc_mpn import graphs
 
 
 def scenario(n_ids: int = 30, n_cams: int = 4, seed: int = 0, p_seen: float = 0.8, fp_rate: float = 0.002,

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import torch
 
-from mtmc_mpn import pp_cases
+import pp_cases
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 NAMES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "pp*.npz")))

@@ -3,7 +3,7 @@ import pytest
 import torch
 
 import mtmc_mpn
-from mtmc_mpn import pp_cases
+import pp_cases
 from oracle import postprocess_oracle as po
 from pp_util import NAMES, PpCase
 
