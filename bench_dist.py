@@ -49,6 +49,17 @@ def main_distributed(args):
     own = rr is not None                      # ... and the rank encodes exactly the rows it projects: h0 stays home too
     lo, hi = mdist.tile_rows(rr, n)[rank] if own else mdist.even_ranges(n, world)[rank]
     x_loc = full.x[lo:hi].clone()
+    # parity of the sharded path against the ONE-GPU forward of the same graph (every rank holds the full graph at
+    # this point): sampled edges of this rank's slice and sampled rows of the node state, checked after the timing
+    with torch.no_grad():
+        mono, mono_h = model(full)
+        stride = max(1, (ehi - elo) // 200_000)
+        ref_logits = mono["classified_edges"][-1][elo:ehi:stride].clone()
+        ref_h = mono_h[::max(1, n // 50_000)].clone()
+        del mono, mono_h
+    model._engine = None
+    from mtmc_mpn import torch_ops
+    torch_ops._ENGINES.clear()                 # drops the monolithic call's workspace
     del full
     torch.cuda.empty_cache()
 
@@ -70,6 +81,16 @@ def main_distributed(args):
     t = torch.tensor([(t1 - t0) / args.steps], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     sec = float(t.item())
+    with torch.no_grad():
+        out, h = step()
+        d_logit = (out["classified_edges"][-1][::stride] - ref_logits).abs().max()
+        d_h = (h[::max(1, n // 50_000)] - ref_h).abs().max() / ref_h.abs().max().clamp_min(1.0)
+    par = torch.stack([d_logit.double(), d_h.double()])
+    dist.all_reduce(par, op=dist.ReduceOp.MAX)
+    parity = {"max_abs_logit_diff_vs_1gpu": float(par[0]), "max_rel_h_diff_vs_1gpu": float(par[1]),
+              "edges_checked_per_rank": int(ref_logits.shape[0]), "tolerance": 1e-4}
+    if not (parity["max_abs_logit_diff_vs_1gpu"] <= 1e-4 and parity["max_rel_h_diff_vs_1gpu"] <= 1e-4):
+        raise RuntimeError(f"sharded forward differs from the 1-GPU forward: {parity}")
 
     # side measurement: the same forward with the node state left sharded (no final [N,32] all-gather) -- the callers of
     # the reference never read latent_node_feats; `value` above is the forward WITH the replicated output
@@ -170,7 +191,7 @@ def main_distributed(args):
                                  "headline"),
                 "forward_algorithmic": {"bytes": b_fwd, "GBps": b_fwd / sec / 1e9,
                                         "frac_of_aggregate_hbm_peak": b_fwd / sec / 1e9 / (bench.HBM_PEAK_GBS * world)},
-                "rank0_split": split,
+                "rank0_split": split, "parity_vs_1gpu": parity,
                 "ms_per_step_with_sharded_node_state": None if sec_sharded_h is None else sec_sharded_h * 1e3}
         print(json.dumps(line))
     dist.destroy_process_group()

@@ -37,15 +37,20 @@ def _case(agg):
     return d, p
 
 
-def _worker(rank, world, port, agg, snap, out_dir, own=False):
+def _worker(rank, world, port, agg, snap, out_dir, own=False, backend="gloo"):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import mtmc_mpn
     from mtmc_mpn import distributed as mdist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # gloo: all ranks share cuda:0 (the 1-GPU test box);  nccl (= RCCL): one GPU per rank, as bench.py --gpus N runs it
+    dev = torch.device(f"cuda:{rank}" if backend == "nccl" else "cuda:0")
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        dev = torch.device("cuda:0")
         d, p = _case(agg)
         torch.manual_seed(0)
         model = mtmc_mpn.MOTMPNet(copy.deepcopy(p), None, "resnet101").to(dev).eval()
@@ -73,12 +78,25 @@ def _worker(rank, world, port, agg, snap, out_dir, own=False):
                                                 (2, "max", True, True), (3, "sum+gaps", True, True),
                                                 (3, "mean+big", True, True), (2, "sum+big", False, False)])
 def test_sharded_forward_on_the_gpu_kernels(world, agg, snap, own, tmp_path):
+    _run_and_compare(world, agg, snap, own, tmp_path, "gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL path at world size 2 needs two GPUs (the driver's 8-GPU node)")
+@pytest.mark.parametrize("agg,snap,own", [("sum", False, False), ("mean", True, False), ("max", True, True),
+                                          ("sum+gaps", True, True), ("mean+big", True, True), ("sum+big", False, False)])
+def test_sharded_forward_over_rccl_two_gpus(agg, snap, own, tmp_path):
+    """The `nccl` branches of distributed.py (all_gather_into_tensor of Pc / h0 / the final h, device-side row_ranges_of)
+    with one GPU per rank: general shards, row-complete shards and own_rows, against the single-GPU forward."""
+    _run_and_compare(2, agg, snap, own, tmp_path, "nccl")
+
+
+def _run_and_compare(world, agg, snap, own, tmp_path, backend):
     import types
     import mtmc_mpn
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(world, port, agg, snap, str(tmp_path), own), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, agg, snap, str(tmp_path), own, backend), nprocs=world, join=True)
     parts = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt")) for r in range(world)]
     dev = torch.device("cuda:0")
     d, p = _case(agg)
