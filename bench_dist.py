@@ -24,6 +24,12 @@ ARCH = "resnet101"
 
 def main_distributed(args):
     import bench
+    import sys
+    # stdout must carry ONE JSON line: RCCL prints a version banner to the C-level stdout at communicator creation, so
+    # everything but the final line is sent to stderr (file descriptor 1 is pointed at 2 for the duration of the run)
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -193,5 +199,9 @@ def main_distributed(args):
                                         "frac_of_aggregate_hbm_peak": b_fwd / sec / 1e9 / (bench.HBM_PEAK_GBS * world)},
                 "rank0_split": split, "parity_vs_1gpu": parity,
                 "ms_per_step_with_sharded_node_state": None if sec_sharded_h is None else sec_sharded_h * 1e3}
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    os.close(real_stdout)
