@@ -367,6 +367,7 @@ __global__ __launch_bounds__(256) void agg_fixup_kernel(RoundParams p) {
   }
 }
 
+typedef float f32x16c __attribute__((ext_vector_type(16)));
 constexpr int kTileC = 256;   // tile = block size (128 and 512 measured slower at every graph size)
 __global__ __launch_bounds__(kTileC) void pass_c_kernel(RoundParams p) {
   __shared__ float4 tile_e[kTileC];
@@ -374,6 +375,7 @@ __global__ __launch_bounds__(kTileC) void pass_c_kernel(RoundParams p) {
   __shared__ double st[10 + 64];           // e' second moments (10) | z2 sums (32) | z2 sums of squares (32)
   const int k = threadIdx.x & 31;          // channel
   const int hw = threadIdx.x >> 5;         // half-wave
+  if (p.mfma_c && p.flags[0] == 0) return; // row-sorted list: pass_c_mfma_kernel, launched just before, did this round
   const int64_t n_tiles = (p.n_edges + kTileC - 1) / kTileC;
   int64_t tile = blockIdx.x;
   // a tile's operands do not depend on the statistics: fetch the first one before waiting for those
@@ -449,6 +451,236 @@ __global__ __launch_bounds__(kTileC) void pass_c_kernel(RoundParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// pass C for many-edge, row-sorted lists: the 32-wide node-update pre-activation of 32 edges at a time on the matrix
+// cores.  A resident grid of waves takes spans of span_c consecutive 64-edge chunks round-robin.  Per chunk: one coalesced float4 (e') + row id per lane; two
+// v_permlane32_swap turn the four components into the A operands of v_mfma_f32_32x32x2_f32 (A[i][k] = e'_k of edge i),
+// the B operand is the channel's BatchNorm-scaled weight row (constant per lane), so
+//     Z[32 edges][32 channels] = E' . (s_k A_k)^T             2 MFMAs per 32 edges (K = 4)
+// arrives as 16 registers per lane = 16 edges of the lane's channel.  The ReLU and the per-row sums are then 3 VALU ops
+// per register (c0 = s_k (Q[row][k] + b_k) + t_k is one value per lane while the group stays in one row -- the common
+// case at the average degrees this kernel is launched for); runs are carried in registers across groups and chunks and
+// flushed with one 128-byte row of float atomics when the row changes.  Groups that straddle rows take a masked pass
+// per distinct row.  Exact same arithmetic per edge as pass_c_kernel (fp32 FMAs in k order inside the MFMA); sum / mean
+// aggregation, eval mode, non-deterministic mode only -- everything else stays on pass_c_kernel.
+// The walk in pass_c_kernel costs ~4.5 wave-instructions per edge; this one ~1.5.
+// ------------------------------------------------------------------------------------------------
+// 64-edge chunks per wave span (runs are carried inside a span; one span per wave, so the grid balances itself)
+
+__global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int span_c) {
+  __shared__ double st[10 + 64];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: spans, chunks, rows stay scalar
+  const int k = lane & 31, hi = lane >> 5;
+  if (p.flags[0] != 0) return;                               // unsorted rows: pass_c_kernel does this round (block-uniform)
+  stat_gather2(p.stats + kRoundMOff + 4, 10, kMStride, p.stats + kRoundZ2Off, 64, kZ2Stride, st);
+  __syncthreads();
+  float sk, tk;
+  {
+    const float* a = p.un_w + k * p.un_ld + p.un_eoff;
+    const double quad = quad_form(a, 4, st);
+    bn_affine(st[10 + k], st[10 + 32 + k] + quad, p.e_total, p.un_g[k], p.un_bt[k], sk, tk);
+  }
+  const float b0 = sk * p.un_w[k * p.un_ld + p.un_eoff + hi];          // B[kk = hi][j = k] of the two K = 2 steps
+  const float b1 = sk * p.un_w[k * p.un_ld + p.un_eoff + 2 + hi];
+  const float cb = fmaf(sk, p.un_b[k], tk);
+  const bool want_logits = p.logits != nullptr;
+  float cw[2][4] = {}, cbias[2] = {};
+  if (want_logits && p.n_classes == 2)
+    for (int c = 0; c < 2; ++c) {
+      cbias[c] = p.cls_b[c];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cw[c][j] = p.cls_w[c * 4 + j];
+    }
+
+  const int64_t n_chunks = (p.n_edges + 63) / 64;
+  const int64_t n_spans = (n_chunks + span_c - 1) / span_c;
+  const int64_t wave_stride = (int64_t)gridDim.x * 4;
+  for (int64_t span = (int64_t)blockIdx.x * 4 + wid; span < n_spans; span += wave_stride) {
+    int cur = -1;                 // wave-uniform: the row whose partial sum `run` holds (this lane's channel, this half's edges)
+    float run = 0.f;
+    auto flush = [&]() {
+      if (cur >= 0) {
+        const float tot = run + __shfl_xor(run, 32, 64);
+        if (hi == 0) unsafeAtomicAdd(p.h_acc + (int64_t)cur * kH + k, tot);
+      }
+    };
+    const int64_t c_end = min(n_chunks, (span + 1) * span_c);
+    // e' / row ids are fetched one chunk ahead; the Q rows of the chunk's first and last row (all of its rows at the
+    // degrees this kernel runs at) are requested as soon as its row ids are there, ahead of the classifier and the MFMAs
+    float4 ev_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    int rw_n = -1;
+    auto fetch = [&](int64_t chunk) {            // ALWAYS two loads (the counted wait below relies on it): clamped address
+      const int64_t e = min(chunk * 64 + lane, p.n_edges - 1);
+      ev_n = reinterpret_cast<const float4*>(p.e_out)[e];
+      rw_n = p.row32[e];
+    };
+    int qa_row = -1, qb_row = -1;
+    float qa = 0.f, qb = 0.f;
+    auto c0_of = [&](int r) -> float {                         // r wave-uniform
+      const float q = r == qa_row ? qa : (r == qb_row ? qb : p.Q[(int64_t)r * kH + k]);
+      return fmaf(sk, q, cb);
+    };
+    auto account = [&](int r, float part) {                     // add a group's partial sum to row r's run
+      if (r != cur) {
+        flush();
+        cur = r;
+        run = 0.f;
+      }
+      run += part;
+    };
+    // sum of relu over the lane's 16 values.  relu as a signed-integer max: exact for every float (negative values and
+    // -0 have the sign bit set), and free of the canonicalising v_max_f32 x, x, x that fmaxf puts in front
+    auto relu_sum = [&](const f32x16c& acc) -> float {
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        s0 += __int_as_float(max(__float_as_int(acc[i]), 0));
+        s1 += __int_as_float(max(__float_as_int(acc[i + 1]), 0));
+      }
+      return s0 + s1;
+    };
+    const int64_t c0_chunk = span * span_c;
+    fetch(c0_chunk);
+    for (int64_t chunk = c0_chunk; chunk < c_end; ++chunk) {
+      const int64_t e = chunk * 64 + lane;
+      const bool valid = e < p.n_edges;
+      const float4 ev = valid ? ev_n : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int rw = valid ? rw_n : -1;
+      const int n_valid = (int)min((int64_t)64, p.n_edges - chunk * 64);      // scalar
+      qa_row = __builtin_amdgcn_readfirstlane(rw);
+      qb_row = __builtin_amdgcn_readfirstlane(__shfl(rw, n_valid - 1, 64));
+      // The Q lookups of this chunk's first / last row and the NEXT chunk's stream loads are in flight together.  Loads
+      // return in order, so the lookups go out first and are waited for with a COUNTED s_waitcnt that leaves the two
+      // prefetch loads outstanding -- otherwise the stream's HBM latency would sit in every iteration.  They are issued
+      // from inline asm because hipcc would wait vmcnt(0) for a plain load's result here (control flow in between).
+      {
+        const float* pa = p.Q + (int64_t)qa_row * kH + k;
+        const float* pb = p.Q + (int64_t)qb_row * kH + k;
+        asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off"
+                     : "=&v"(qa), "=&v"(qb) : "v"(pa), "v"(pb) : "memory");
+      }
+      fetch(chunk + 1);
+      float lg0 = 0.f, lg1 = 0.f;
+      if (want_logits && p.n_classes == 2) {                    // classifier on this edge (mpn.py:291-292): arithmetic now,
+        // two scalar FMA chains, kept apart: paired up by the SLP vectoriser they become v_pk_fma_f32 with op_sel,
+        // the form tools/check_isa.py bans from kernels with MFMAs
+        lg0 = fmaf(cw[0][3], ev.w, fmaf(cw[0][2], ev.z, fmaf(cw[0][1], ev.y, fmaf(cw[0][0], ev.x, cbias[0]))));
+        asm volatile("" : "+v"(lg0));
+        lg1 = fmaf(cw[1][3], ev.w, fmaf(cw[1][2], ev.z, fmaf(cw[1][1], ev.y, fmaf(cw[1][0], ev.x, cbias[1]))));
+      }
+      // A operands: lanes 0..31 carry component k = 0 (2), lanes 32..63 component k = 1 (3) of edge (lane & 31)
+      const auto xy = __builtin_amdgcn_permlane32_swap(__float_as_uint(ev.x), __float_as_uint(ev.y), false, false);
+      const auto zw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ev.z), __float_as_uint(ev.w), false, false);
+      const unsigned long long row_first_mask = __ballot(rw == qa_row), row_last_mask = __ballot(rw == qb_row);
+      // group g = edges 32g .. 32g+31 of the chunk.  At the degrees this kernel runs at a group touches one row, or two
+      // (a row boundary inside it): classify each group by its first row (mask ma), the row of its first other edge
+      // (mask mb), and whether those two cover it.  All of this is scalar.
+      const int nv1 = n_valid - 32;
+      const unsigned gmv[2] = {n_valid >= 32 ? 0xffffffffu : ((1u << n_valid) - 1u),
+                               nv1 >= 32 ? 0xffffffffu : (nv1 > 0 ? ((1u << nv1) - 1u) : 0u)};
+      int ra[2], rb[2];
+      unsigned ma[2], mb[2];
+      bool two_rows_max[2];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        ra[g] = rb[g] = -1;
+        ma[g] = mb[g] = 0;
+        two_rows_max[g] = true;
+        if (gmv[g] == 0) continue;
+        ra[g] = g == 0 ? qa_row : __builtin_amdgcn_readlane(rw, 32);
+        const unsigned long long fa = g == 0 ? row_first_mask : (ra[g] == qb_row ? row_last_mask : __ballot(rw == ra[g]));
+        ma[g] = (unsigned)(fa >> (32 * g)) & gmv[g];
+        const unsigned rest = gmv[g] & ~ma[g];
+        if (rest != 0) {
+          rb[g] = __builtin_amdgcn_readfirstlane(__shfl(rw, 32 * g + __ffs(rest) - 1, 64));
+          const unsigned long long fb = rb[g] == qb_row ? row_last_mask : __ballot(rw == rb[g]);
+          mb[g] = (unsigned)(fb >> (32 * g)) & gmv[g];
+          two_rows_max[g] = (ma[g] | mb[g]) == gmv[g];
+        }
+      }
+      // Q lookups done (the two prefetch loads may still be in flight); stores only from here on -- they share the counter
+      asm volatile("s_waitcnt vmcnt(2)" : "+v"(qa), "+v"(qb) : : "memory");
+      if (want_logits && valid) {                                // ... the store after the counted wait
+        if (p.n_classes == 2) {
+          reinterpret_cast<float2*>(p.logits)[e] = make_float2(lg0, lg1);
+        } else {
+          for (int c = 0; c < p.n_classes; ++c) {
+            const float* w = p.cls_w + c * 4;
+            p.logits[e * p.n_classes + c] = fmaf(w[3], ev.w, fmaf(w[2], ev.z, fmaf(w[1], ev.y, fmaf(w[0], ev.x, p.cls_b[c]))));
+          }
+        }
+      }
+      if (two_rows_max[0] && two_rows_max[1]) {
+        // Z = c0[row of edge] + E' . (s A)^T: the row constants ride in as a third K step whose A operand is the
+        // membership of edge i in the group's first / second row and whose B operand holds the two constants; both
+        // groups' chains are issued before either result is consumed
+        f32x16c acc[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const unsigned long long member = (unsigned long long)ma[g] | ((unsigned long long)mb[g] << 32);
+          const float a_c = __builtin_amdgcn_inverse_ballot_w64(member) ? 1.0f : 0.0f;
+          const float c_a = ra[g] >= 0 ? c0_of(ra[g]) : 0.f, c_b = rb[g] >= 0 ? c0_of(rb[g]) : 0.f;
+          f32x16c z = {};
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c, hi == 0 ? c_a : c_b, z, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(xy[g]), b0, acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(zw[g]), b1, acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          if (ra[g] < 0) break;
+          const float total = relu_sum(acc[g]);
+          if (rb[g] < 0) {
+            account(ra[g], total);
+          } else {                                             // the first row's share through per-register lane masks
+            float sa0 = 0.f, sa1 = 0.f;                        // (register i = edge (i&3) + 8(i>>2) + 4*hi of the group)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int c = (i & 3) + 8 * (i >> 2);
+              const unsigned long long in_a = (((ma[g] >> c) & 1u) ? 0xffffffffull : 0ull) |
+                                              (((ma[g] >> (c + 4)) & 1u) ? 0xffffffff00000000ull : 0ull);
+              const float t = __int_as_float(max(__float_as_int(acc[g][i]), 0));
+              const float v = __builtin_amdgcn_inverse_ballot_w64(in_a) ? t : 0.f;
+              if (i & 1) sa1 += v; else sa0 += v;
+            }
+            const float sa = sa0 + sa1;
+            account(ra[g], sa);
+            account(rb[g], total - sa);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const unsigned gm = gmv[g];
+          if (gm == 0) break;
+          f32x16c acc = {};
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(xy[g]), b0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(zw[g]), b1, acc, 0, 0, 0);
+          unsigned done = 0;
+          while (done != gm) {                                   // one masked pass per distinct row of the group
+            const int pos = __ffs(gm & ~done) - 1;
+            const int r = __builtin_amdgcn_readfirstlane(__shfl(rw, 32 * g + pos, 64));
+            const unsigned same = (unsigned)(__ballot(rw == r) >> (32 * g)) & gm & ~done;
+            done |= same;
+            const float c0 = c0_of(r);
+            const unsigned mine = same >> (4 * hi);             // bit (i&3) + 8(i>>2): register i's edge of this half-wave
+            float sacc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const float t = fmaxf(acc[i] + c0, 0.f);
+              sacc += ((mine >> ((i & 3) + 8 * (i >> 2))) & 1u) ? t : 0.f;
+            }
+            account(r, sacc);
+          }
+        }
+      }
+    }
+    flush();
+  }
+}
+
 __global__ __launch_bounds__(256) void classify_e0_kernel(EdgeEncParams enc, const float* attr, int64_t n_edges,
                                                           double e_total, const float* cls_w, const float* cls_b,
                                                           int n_classes, float* logits) {
@@ -513,7 +745,26 @@ void launch_pass_b(const RoundParams& p, hipStream_t s) {
     default: hipLaunchKernelGGL(pass_b_kernel<4>, dim3(edge_grid(p.n_edges, 1024)), dim3(256), 0, s, p);
   }
 }
-void launch_pass_c(const RoundParams& p, hipStream_t s) {
+// Many edges per node on a many-edge list: the matrix-core kernel (it returns at once when prep_kernel found the rows
+// unsorted, and pass_c_kernel, launched behind it, returns at once when they are sorted: sortedness is only known on
+// the device).  MTMC_PASS_C_WALK=1 keeps the walk everywhere (A/B).
+static bool use_mfma_c(const RoundParams& p) {
+  static const bool off = getenv("MTMC_PASS_C_WALK") != nullptr;
+  return !off && p.agg != 2 && !p.det && !p.drop_n.on && p.n_edges > kSmallEdges && p.n_nodes > 0 &&
+         p.n_edges / p.n_nodes >= 24;
+}
+
+void launch_pass_c(const RoundParams& p0, hipStream_t s) {
+  RoundParams p = p0;
+  p.mfma_c = use_mfma_c(p) ? 1 : 0;
+  if (p.mfma_c) {
+    // a resident grid (the block prologue -- 74 replicated statistics, one BatchNorm affine per channel -- is paid once
+    // per block, so blocks live long) whose waves take short spans round-robin (balance: ~6 spans per wave at config 4)
+    static const int span_c = getenv("MTMC_PASS_C_SPAN") ? atoi(getenv("MTMC_PASS_C_SPAN")) : 8;
+    static const int max_blocks = getenv("MTMC_PASS_C_BLOCKS") ? atoi(getenv("MTMC_PASS_C_BLOCKS")) : 256 * 6;
+    const int64_t spans = ((p.n_edges + 63) / 64 + span_c - 1) / span_c, blocks = (spans + 3) / 4;
+    hipLaunchKernelGGL(pass_c_mfma_kernel, dim3((int)(blocks > max_blocks ? max_blocks : blocks)), dim3(256), 0, s, p, span_c);
+  }
   hipLaunchKernelGGL(pass_c_kernel, dim3(edge_grid(p.n_edges, kTileC)), dim3(kTileC), 0, s, p);
   if (p.det && p.agg != 2) {
     const int64_t blocks = (p.n_nodes + 7) / 8;

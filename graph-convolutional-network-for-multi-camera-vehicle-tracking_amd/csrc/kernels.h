@@ -38,6 +38,7 @@ struct RoundParams {
   float* logits;             // this round's [E][C] output or nullptr
   int64_t n_edges; double e_total;
   int first_round; int reattach_edges; int agg;
+  int mfma_c;                // set by launch_pass_c: the matrix-core pass C takes row-sorted lists
   int det; const int* flags; const int* deg; const int* row_start; float* carry; int64_t n_nodes;   // deterministic sums
   EdgeEncParams enc;
 };

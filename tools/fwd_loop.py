@@ -19,5 +19,5 @@ params = mtmc_mpn.default_params(num_enc_steps=L, num_class_steps=cs)
 torch.manual_seed(0)
 model = mtmc_mpn.MOTMPNet(copy.deepcopy(params), None, "resnet101").to(dev).eval()
 data = bench.make_workload(name, dev)
-sec = bench.time_forward(model, data, iters, 10)
+sec, _ = bench.time_forward(model, data, iters, 10)
 print(f"{name}: {sec * 1e6:.1f} us/forward")
