@@ -127,7 +127,7 @@ def phase_cost(ph, arg, spec, n, e):
         _lib.PH_NODE_H0: 256 * n,
         _lib.PH_ROUND_PROJ: (128 + 32 + 128 + 128) * n,                # h in, P, Q out, cleared aggregation buffer
         _lib.PH_ROUND_A: (8 + e_in + 16) * e + 32 * n,                 # row/col + e_in read, z1 written, P table once
-        _lib.PH_ROUND_B: (4 + 16 + 16) * e + 32 * n,                   # row + z1 read, e' written, segment sums
+        _lib.PH_ROUND_B: (4 + 16 + (0 if e > 2048 * 256 else 16)) * e + 32 * n,   # row + z1 read, segment sums (+ e' written on few-edge graphs)
         _lib.PH_ROUND_STAT: (128 + 4 + 32) * n,
         _lib.PH_ROUND_C: (4 + 16) * e + (128 + 128) * n + (8 * e if arg >= spec.num_enc_steps - spec.num_class_steps else 0),
         _lib.PH_END: 256 * n,

@@ -257,6 +257,9 @@ inline mtmc::RoundParams round_params(const Ctx& x, int r) {
   p.un_ld = m->upd_node.in_dim; p.un_eoff = hn;
   p.cls_w = m->cls.weight; p.cls_b = m->cls.bias; p.n_classes = m->cls.out_dim;
   p.stats = x.at<double>(x.lo.pub.stat_round_off) + (size_t)r * mtmc::kRoundBlock;
+  // (few-edge graphs are latency-bound: there the extra statistics gather in two prologues costs more than the bytes save)
+  p.lazy_e = (!x.lo.training && x.c->n_edges > 2048 * 256) ? 1 : 0;
+  p.prev_stats = r > 0 ? p.stats - mtmc::kRoundBlock : nullptr;
   p.seg = x.at<double>(x.lo.pub.seg_off);
   p.h_acc = agg_target(x, r);
   const int step = r + 1;

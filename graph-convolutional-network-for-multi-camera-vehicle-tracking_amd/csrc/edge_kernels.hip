@@ -138,8 +138,10 @@ __device__ __forceinline__ void load_edge_upd_weights(const RoundParams& p, Edge
   }
 }
 
+struct PrevAffine { float s[4], t[4]; };   // BatchNorm affine of the previous round's z1 (lazy e')
+
 __device__ __forceinline__ void edge_z1(const RoundParams& p, const EdgeEncAffine& af, const EdgeUpdWeights& w,
-                                        int64_t e, int& r, float (&z)[4]) {
+                                        const PrevAffine& pa, int64_t e, int& r, float (&z)[4]) {
   r = p.row32[e];
   const int c = p.col32[e];
   // P = [Pr: N x 4 | Pc: N x 4]: the randomly gathered half is a compact 16 B/node table (four nodes per 64-byte sector)
@@ -158,6 +160,10 @@ __device__ __forceinline__ void edge_z1(const RoundParams& p, const EdgeEncAffin
   } else {
     const float4 v = reinterpret_cast<const float4*>(p.e_prev)[e];
     ep[0] = v.x; ep[1] = v.y; ep[2] = v.z; ep[3] = v.w;
+    if (p.lazy_e) {                               // the buffer holds the previous round's z1: e' = relu(bn(z1))
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ep[j] = fmaxf(fmaf(ep[j], pa.s[j], pa.t[j]), 0.f);
+    }
   }
   const float prv[4] = {pr.x, pr.y, pr.z, pr.w}, pcv[4] = {pc.x, pc.y, pc.z, pc.w};
 #pragma unroll
@@ -183,7 +189,19 @@ template <int kEPT>
 __global__ __launch_bounds__(256) void pass_a_kernel(RoundParams p) {
   __shared__ EdgeEncAffine af;
   __shared__ double red[8 * 4];
+  __shared__ PrevAffine pa_s;
   if (p.first_round || p.reattach_edges) edge_enc_affine_load(p.enc, &af);
+  if (p.lazy_e && !p.first_round) {
+    stat_gather(p.prev_stats + kRoundZ1Off, 8, kZ1Stride, red);
+    __syncthreads();
+    if (threadIdx.x < 4)
+      bn_affine(red[threadIdx.x], red[4 + threadIdx.x], p.e_total, p.ue_g[threadIdx.x], p.ue_bt[threadIdx.x],
+                pa_s.s[threadIdx.x], pa_s.t[threadIdx.x]);
+    __syncthreads();
+  }
+  PrevAffine pa;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { pa.s[j] = pa_s.s[j]; pa.t[j] = pa_s.t[j]; }
   EdgeUpdWeights w;
   load_edge_upd_weights(p, w);
   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -195,7 +213,7 @@ __global__ __launch_bounds__(256) void pass_a_kernel(RoundParams p) {
       const int64_t e = base + i * 256;
       int r;
       if (e < p.n_edges) {
-        edge_z1(p, af, w, e, r, z[i]);
+        edge_z1(p, af, w, pa, e, r, z[i]);
         // the random 16-byte P[col] gather is what bounds this pass (one cache line per lane): do it once and
         // hand z1 to pass B through memory instead of gathering again there
         reinterpret_cast<float4*>(p.e_buf)[e] = make_float4(z[i][0], z[i][1], z[i][2], z[i][3]);
@@ -262,7 +280,7 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           vv[i][k] = drop_apply(p.drop_e, p.drop_stream, (unsigned long long)e * 4 + k, fmaxf(fmaf(z4[k], s1[k], t1[k]), 0.f));
-        reinterpret_cast<float4*>(p.e_out)[e] = make_float4(vv[i][0], vv[i][1], vv[i][2], vv[i][3]);
+        if (!p.lazy_e) reinterpret_cast<float4*>(p.e_out)[e] = make_float4(vv[i][0], vv[i][1], vv[i][2], vv[i][3]);
       }
     }
 #pragma unroll
@@ -393,7 +411,16 @@ __global__ __launch_bounds__(kTileC) void pass_c_kernel(RoundParams p) {
   if (tile < n_tiles) fetch(tile);
   // BatchNorm affine of channel k of z2 from the moment statistics (node_stat_kernel + pass B)
   stat_gather2(p.stats + kRoundMOff + 4, 10, kMStride, p.stats + kRoundZ2Off, 64, kZ2Stride, st);
+  __shared__ double st1[8];
+  __shared__ float s1[4], t1[4];
+  if (p.lazy_e) stat_gather(p.stats + kRoundZ1Off, 8, kZ1Stride, st1);
   __syncthreads();
+  if (p.lazy_e) {                          // the edge buffer holds z1: e' = relu(s1 z1 + t1), recomputed here
+    if (threadIdx.x < 4)
+      bn_affine(st1[threadIdx.x], st1[4 + threadIdx.x], p.e_total, p.ue_g[threadIdx.x], p.ue_bt[threadIdx.x],
+                s1[threadIdx.x], t1[threadIdx.x]);
+    __syncthreads();
+  }
   float sk, tk;
   {
     const float* a = p.un_w + k * p.un_ld + p.un_eoff;
@@ -409,6 +436,10 @@ __global__ __launch_bounds__(kTileC) void pass_c_kernel(RoundParams p) {
   while (tile < n_tiles) {
     const int64_t base = tile * kTileC;
     const int64_t e = base + threadIdx.x;
+    if (p.lazy_e) {
+      ev.x = fmaxf(fmaf(ev.x, s1[0], t1[0]), 0.f); ev.y = fmaxf(fmaf(ev.y, s1[1], t1[1]), 0.f);
+      ev.z = fmaxf(fmaf(ev.z, s1[2], t1[2]), 0.f); ev.w = fmaxf(fmaf(ev.w, s1[3], t1[3]), 0.f);
+    }
     if (e < p.n_edges) {
       tile_row[threadIdx.x] = rw;
       if (p.logits) {                                         // classifier on this edge (mpn.py:291-292)
@@ -474,7 +505,19 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
   const int k = lane & 31, hi = lane >> 5;
   if (p.flags[0] != 0) return;                               // unsorted rows: pass_c_kernel does this round (block-uniform)
   stat_gather2(p.stats + kRoundMOff + 4, 10, kMStride, p.stats + kRoundZ2Off, 64, kZ2Stride, st);
+  __shared__ double st1[8];
+  __shared__ float s1s[4], t1s[4];
+  if (p.lazy_e) stat_gather(p.stats + kRoundZ1Off, 8, kZ1Stride, st1);
   __syncthreads();
+  float s1[4] = {1.f, 1.f, 1.f, 1.f}, t1[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.lazy_e) {                                            // the edge buffer holds z1: e' = relu(s1 z1 + t1), recomputed here
+    if (threadIdx.x < 4)
+      bn_affine(st1[threadIdx.x], st1[4 + threadIdx.x], p.e_total, p.ue_g[threadIdx.x], p.ue_bt[threadIdx.x],
+                s1s[threadIdx.x], t1s[threadIdx.x]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s1[j] = s1s[j]; t1[j] = t1s[j]; }
+  }
   float sk, tk;
   {
     const float* a = p.un_w + k * p.un_ld + p.un_eoff;
@@ -545,7 +588,14 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
     for (int64_t chunk = c0_chunk; chunk < c_end; ++chunk) {
       const int64_t e = chunk * 64 + lane;
       const bool valid = e < p.n_edges;
-      const float4 ev = valid ? ev_n : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 ev = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (valid) {
+        ev = ev_n;
+        if (p.lazy_e) {
+          ev.x = fmaxf(fmaf(ev.x, s1[0], t1[0]), 0.f); ev.y = fmaxf(fmaf(ev.y, s1[1], t1[1]), 0.f);
+          ev.z = fmaxf(fmaf(ev.z, s1[2], t1[2]), 0.f); ev.w = fmaxf(fmaf(ev.w, s1[3], t1[3]), 0.f);
+        }
+      }
       const int rw = valid ? rw_n : -1;
       const int n_valid = (int)min((int64_t)64, p.n_edges - chunk * 64);      // scalar
       qa_row = __builtin_amdgcn_readfirstlane(rw);

@@ -38,6 +38,9 @@ struct RoundParams {
   float* logits;             // this round's [E][C] output or nullptr
   int64_t n_edges; double e_total;
   int first_round; int reattach_edges; int agg;
+  // eval mode: e' = relu(bn(z1)) is never written -- pass C and the next round's pass A recompute it from z1 (4 FMAs)
+  // with the round's z1 statistics; pass B only reduces it.  16 B/edge/round less traffic.  prev_stats: round r-1's block
+  int lazy_e; const double* prev_stats;
   int mfma_c;                // set by launch_pass_c: the matrix-core pass C takes row-sorted lists
   int det; const int* flags; const int* deg; const int* row_start; float* carry; int64_t n_nodes;   // deterministic sums
   EdgeEncParams enc;
