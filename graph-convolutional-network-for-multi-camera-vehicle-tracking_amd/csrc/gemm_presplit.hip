@@ -269,6 +269,183 @@ __global__ __launch_bounds__(BT * 2, MINB) void gemm_f16p_kernel(SplitGemmParams
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 tile, BK = 32, two LDS stages, ONE barrier per k-tile placed in the MIDDLE of the tile's MFMAs, fragments
+// double-buffered in registers.  In gemm_f16p_kernel every k-tile starts with all eight waves behind a barrier with
+// empty fragment registers: the matrix pipes idle for a whole LDS round trip per tile.  Here a k-tile's two 16-deep
+// steps alternate between two fragment sets:
+//     issue reads  F1 <- (tile k, step 1)                      | the reads fly under the MFMAs on F0
+//     24 MFMAs on F0 (tile k, step 0)
+//     wait own reads + own LDS-DMA of tile k+1; BARRIER         | every wave is done reading tile k's stage
+//     issue LDS-DMA tile k+2 -> the stage tile k leaves; issue reads F0 <- (tile k+1, step 0)
+//     24 MFMAs on F1 (tile k, step 1)                           | the new reads and the DMA fly under these
+// so after the barrier the waves have 24 MFMAs each queued with operands already in registers.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void gemm_f16p_mid_kernel(SplitGemmParams p, int tiles_m, int tiles_n) {
+  constexpr int BT = 256, BK = 32, NT = 512, TI = 4, ROWB = BK * 2, IMG = BT * ROWB, STAGE = 4 * IMG;
+  constexpr int SLOTS = BK / 8, RPI = NT / SLOTS, IPI = BT / RPI;       // 4 slots, 128 rows per instruction, 2 per image
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tm_idx = (slot / tiles_n) * 8 + xcd, tn_idx = slot % tiles_n;
+  if (tm_idx >= tiles_m) return;
+  const int64_t m0 = (int64_t)tm_idx * BT;
+  const int n0 = tn_idx * BT;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wm = wid / 4, wn = wid % 4;
+
+  const int r0 = threadIdx.x / SLOTS, sp = threadIdx.x % SLOTS;
+  const int gsrc = (r0 >> 2) & 3;
+  const int scol = (sp ^ gsrc) * 8;
+  // two base pointers per thread (its row of the A / W tile); the second piece, the second 128-row half and the k-tile
+  // are uniform offsets added at issue time -- eight resident 64-bit pointers would not fit beside the fragments
+  const int64_t ar0 = m0 + r0 < p.M ? m0 + r0 : p.M - 1, ar1 = m0 + r0 + RPI < p.M ? m0 + r0 + RPI : p.M - 1;
+  const int64_t br0 = n0 + r0 < p.Nout ? n0 + r0 : p.Nout - 1, br1 = n0 + r0 + RPI < p.Nout ? n0 + r0 + RPI : p.Nout - 1;
+  const _Float16* a_base = p.Ah + ar0 * p.K + scol;
+  const _Float16* w_base = p.Wh + br0 * p.K + scol;
+  const int a_step = (int)(ar1 - ar0) * p.K, w_step = (int)(br1 - br0) * p.K;   // elements to the thread's second row
+  const int64_t a_plane = p.M * (int64_t)p.K, w_plane = (int64_t)p.Nout * p.K;
+  auto issue = [&](int kt, int buf) {
+    unsigned char* st = smem + buf * STAGE + wid * 1024;
+#pragma unroll
+    for (int im = 0; im < 4; ++im)
+#pragma unroll
+      for (int j = 0; j < IPI; ++j) {
+        const _Float16* g = (im < 2 ? a_base : w_base) + (im & 1 ? (im < 2 ? a_plane : w_plane) : 0) +
+                            (j ? (im < 2 ? a_step : w_step) : 0) + kt * BK;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(st + im * IMG + j * (NT * 16)), 16, 0, 0);
+      }
+  };
+  const int fr = lane & 31, hi = lane >> 5;
+  const int gl = (fr >> 2) & 3;
+  const int a_row = (wm * TI * 32 + fr) * ROWB, b_row = (wn * 64 + fr) * ROWB;
+  const int sx = (hi ^ gl) * 16;
+
+  f32x16 acc[TI][2];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f16x8 fa[2][TI][2], fb[2][2][2];                  // [fragment set][block][piece]
+  auto read_frags = [&](int set, int buf, int ks) {
+    const unsigned char* st = smem + buf * STAGE;
+    const int so = sx ^ (ks * 32);
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) fa[set][i][q] = *reinterpret_cast<const f16x8*>(st + q * IMG + a_row + i * 32 * ROWB + so);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) fb[set][j][q] = *reinterpret_cast<const f16x8*>(st + (2 + q) * IMG + b_row + j * 32 * ROWB + so);
+  };
+  auto mfmas = [&](int set) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][i][1], fb[set][j][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][i][0], fb[set][j][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][i][0], fb[set][j][0], acc[i][j], 0, 0, 0);
+      }
+  };
+
+  const int nk = p.K / BK;
+  issue(0, 0);
+  if (nk > 1) {
+    issue(1, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * IPI) : "memory");    // tile 0 landed (tile 1 may still fly)
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  read_frags(0, 0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    read_frags(1, buf, 1);                                             // step 1 of this tile: flies under the MFMAs below
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(0);
+    __builtin_amdgcn_sched_barrier(0);
+    // this wave's reads of stage `buf` are done, and its share of tile kt+1 has landed in the other stage
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) issue(kt + 2, buf);                               // the stage tile kt leaves
+    if (kt + 1 < nk) read_frags(0, buf ^ 1, 0);                        // step 0 of the next tile
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // ---- epilogue (as gemm_f16p_kernel)
+  __syncthreads();
+  double* colred = reinterpret_cast<double*>(smem);
+  float ymax = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int cl = wn * 64 + j * 32 + fr;
+    const int col = n0 + cl;
+    const bool cok = col < p.Nout;
+    const float bias = cok ? p.bias[col] : 0.f;
+    const float iw = cok ? p.inv_w[col] : 0.f;
+    double cs = 0, cq = 0;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * TI * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (row < p.M && cok) {
+          const float y = fmaf(acc[i][j][r] * p.inv_a[row], iw, bias);
+          p.Y[row * p.ldy + col] = y;
+          ymax = fmaxf(ymax, fabsf(y));
+          cs += y;
+          cq += (double)y * y;
+        }
+      }
+    }
+    cs += __shfl_xor(cs, 32, 64);
+    cq += __shfl_xor(cq, 32, 64);
+    if (lane < 32) {
+      colred[(wm * 2 + 0) * BT + cl] = cs;
+      colred[(wm * 2 + 1) * BT + cl] = cq;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * BT; i += NT) {
+    const int which = i / BT, cl = i % BT, col = n0 + cl;
+    if (col < p.Nout && p.stats_out)
+      unsafeAtomicAdd(p.stats_out + which * p.Nout + col, colred[(0 * 2 + which) * BT + cl] + colred[(1 * 2 + which) * BT + cl]);
+  }
+  if (p.amax_y) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, off, 64));
+    __syncthreads();
+    float* wmax = reinterpret_cast<float*>(smem);
+    if (lane == 0) wmax[wid] = ymax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = wmax[0];
+#pragma unroll
+      for (int w = 1; w < NT / 64; ++w) m = fmaxf(m, wmax[w]);
+      atomicMax(p.amax_y + (blockIdx.x % kAmaxRep), __float_as_uint(m));
+    }
+  }
+}
+
+static void launch_mid(const SplitGemmParams& p, hipStream_t s) {
+  const int tiles_m = (int)((p.M + 255) / 256), tiles_n = (p.Nout + 255) / 256;
+  const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
+  const size_t lds = (size_t)2 * 4 * 256 * 32 * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16p_mid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_f16p_mid_kernel, dim3(grid), dim3(512), lds, s, p, tiles_m, tiles_n);
+}
+
 template <int BT, int BK, int NBUF, int MINB>
 static void launch_variant(const SplitGemmParams& p, hipStream_t s) {
   const int tiles_m = (int)((p.M + BT - 1) / BT), tiles_n = (p.Nout + BT - 1) / BT;
@@ -295,6 +472,7 @@ int launch_gemm_presplit(const SplitGemmParams& p, hipStream_t s, int variant) {
     case 6: launch_variant<256, 16, 4, 1>(p, s); break;       // counted-vmcnt pipeline, three k-tiles in flight
     case 7: launch_variant<256, 16, 3, 1>(p, s); break;
     case 8: launch_variant<128, 32, 3, 1>(p, s); break;
+    case 9: launch_mid(p, s); break;                          // mid-tile barrier, fragments double-buffered
     default: launch_variant<256, 32, 2, 1>(p, s); break;
   }
   return 0;

@@ -11,6 +11,7 @@ import torch  # noqa: E402
 from mtmc_mpn import _lib  # noqa: E402
 
 lib = _lib.load()
+VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "0,9").split(",")]
 s = torch.cuda.current_stream().cuda_stream
 
 
@@ -30,7 +31,7 @@ def check(M, K, N):
     scr = torch.zeros(48, dtype=torch.int32, device="cuda")
     st = torch.empty(2 * N, dtype=torch.float64, device="cuda")
     scale = (A.double().abs() @ W.double().abs().t()) + b.double().abs()          # per-element sum |a||w|
-    for variant in range(9):
+    for variant in range(10):
         Y = torch.full((M, N), float("nan"), device="cuda")
         run(M, K, N, variant, A, W, b, Y, work, scr, st)
         torch.cuda.synchronize()
@@ -73,7 +74,7 @@ def timeit(M, K, N, iters=20):
     base = t(lambda: lib.mtmc_linear_raw(A.data_ptr(), K, W.data_ptr(), b.data_ptr(), Y.data_ptr(), M, K, N, scr.data_ptr(),
                                          st.data_ptr(), s))
     print(f"M={M} K={K} N={N}: in-loop split (|.|max pass + GEMM) {base:.1f} us", flush=True)
-    for variant in [0, 1, 2, 3, 4, 5, 6, 7, 8]:
+    for variant in VARIANTS:
         full = t(lambda: run(M, K, N, variant, A, W, b, Y, work, scr, st))
         gemm = t(lambda: run(M, K, N, -variant - 1, A, W, b, Y, work, scr, st))
         print(f"  variant {variant}: split + GEMM {full:.1f} us, GEMM alone {gemm:.1f} us = "
