@@ -61,7 +61,7 @@ EXPORTS = ["mtmc_mpn_abi_version", "mtmc_mpn_last_error", "mtmc_mpn_workspace_by
            "mtmc_mlp_layer_forward", "mtmc_mpn_train_workspace_bytes", "mtmc_mpn_backward", "mtmc_graph_workspace_bytes",
            "mtmc_build_graph", "mtmc_postprocess_workspace_bytes", "mtmc_postprocess",
            "mtmc_cross_entropy_forward", "mtmc_cross_entropy_backward",
-           "mtmc_cross_entropy_steps_forward", "mtmc_cross_entropy_steps_backward", "mtmc_mpn_backward_steps", "mtmc_linear_raw", "mtmc_edge_confusion",
+           "mtmc_cross_entropy_steps_forward", "mtmc_cross_entropy_steps_backward", "mtmc_mpn_backward_steps", "mtmc_mpn_backward_flat", "mtmc_mpn_grad_layout", "mtmc_linear_raw", "mtmc_edge_confusion",
            "mtmc_linear_presplit_raw"]
 
 _lib = None
@@ -98,6 +98,11 @@ def load() -> C.CDLL:
     lib.mtmc_mpn_backward_steps.restype = C.c_int32
     lib.mtmc_mpn_backward_steps.argtypes = [C.POINTER(Model), C.POINTER(Call), C.POINTER(C.c_void_p), C.c_void_p,
                                             C.POINTER(Model), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.mtmc_mpn_backward_flat.restype = C.c_int32
+    lib.mtmc_mpn_backward_flat.argtypes = [C.POINTER(Model), C.POINTER(Call), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
+                                           C.c_int64, C.c_void_p, C.c_void_p]
+    lib.mtmc_mpn_grad_layout.restype = C.c_int64
+    lib.mtmc_mpn_grad_layout.argtypes = [C.POINTER(Model), C.POINTER(C.c_int64), C.c_int32]
     lib.mtmc_edge_confusion.restype = C.c_int32
     lib.mtmc_edge_confusion.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
     lib.mtmc_linear_presplit_raw.restype = C.c_int32

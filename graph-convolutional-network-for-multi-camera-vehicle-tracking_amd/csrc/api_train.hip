@@ -237,3 +237,52 @@ extern "C" int32_t mtmc_mpn_backward_steps(const mtmc_mpn_model* model, const mt
                                            float* d_x, float* d_edge_attr) {
   return backward_impl(model, call, d_logits_steps, d_h, grads, grads_flat, grads_flat_bytes, d_x, d_edge_attr);
 }
+
+// The same with the gradient carving done here: `flat` (fp32, flat_floats long) receives every parameter gradient in
+// struct order -- node encoder layers, edge encoder, edge update, node update, classifier; weight, bias, then gamma, beta
+// where the layer has a BatchNorm -- each piece starting on a 64-float (256-byte) boundary.  The host makes ONE allocation
+// and views it with the same rule (mtmc_mpn_grad_layout: offsets in floats, returns the total), instead of filling a
+// second 34-pointer struct per call.
+extern "C" int64_t mtmc_mpn_grad_layout(const mtmc_mpn_model* m, int64_t* offsets, int32_t max_offsets) {
+  if (!m) return 0;
+  int64_t total = 0;
+  int n = 0;
+  auto piece = [&](int64_t numel) {
+    if (offsets && n < max_offsets) offsets[n] = total;
+    ++n;
+    total += (numel + 63) / 64 * 64;
+  };
+  auto layer = [&](const mtmc_layer& l, bool bn) {
+    piece((int64_t)l.out_dim * l.in_dim);
+    piece(l.out_dim);
+    if (bn) { piece(l.out_dim); piece(l.out_dim); }
+  };
+  for (int l = 0; l < m->n_enc_layers; ++l) layer(m->enc_node[l], true);
+  layer(m->enc_edge[0], true); layer(m->enc_edge[1], true);
+  layer(m->upd_edge, true); layer(m->upd_node, true);
+  layer(m->cls, false);
+  return total;
+}
+
+extern "C" int32_t mtmc_mpn_backward_flat(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
+                                          const float* const* d_logits_steps, const float* d_h, float* flat,
+                                          int64_t flat_floats, float* d_x, float* d_edge_attr) {
+  if (!model || !flat) return fail(MTMC_E_ARG, "mtmc_mpn_backward_flat: NULL model or gradient buffer");
+  int64_t off[4 * (MTMC_MAX_ENC_LAYERS + 4) + 2];
+  const int64_t need = mtmc_mpn_grad_layout(model, off, (int32_t)(sizeof(off) / sizeof(off[0])));
+  if (flat_floats < need) return fail(MTMC_E_ARG, "mtmc_mpn_backward_flat: gradient buffer too small");
+  mtmc_mpn_model g = *model;
+  int n = 0;
+  auto layer = [&](mtmc_layer& l, bool bn) {
+    l.weight = flat + off[n++];
+    l.bias = flat + off[n++];
+    l.gamma = bn ? flat + off[n++] : nullptr;
+    l.beta = bn ? flat + off[n++] : nullptr;
+  };
+  for (int l = 0; l < g.n_enc_layers; ++l) layer(g.enc_node[l], true);
+  layer(g.enc_edge[0], true); layer(g.enc_edge[1], true);
+  layer(g.upd_edge, true); layer(g.upd_node, true);
+  layer(g.cls, false);
+  return backward_impl(model, call, d_logits_steps, d_h, &g, flat, (size_t)need * sizeof(float), d_x, d_edge_attr);
+}
+

@@ -50,8 +50,21 @@ def engine_for(config: str):
     return eng
 
 
+_GRAD_LAYOUTS = {}
+
+
 def grad_layout(spec):
-    """(offset, numel, shape) of every parameter gradient inside the flat buffer mp_backward returns (256-byte pieces)."""
+    """(offset, numel, shape) of every parameter gradient inside the flat buffer mp_backward returns (256-byte pieces;
+    the rule of mtmc_mpn_grad_layout in csrc/api_train.hip)."""
+    hit = _GRAD_LAYOUTS.get(id(spec))
+    if hit is not None:
+        return hit
+    res = _grad_layout(spec)
+    _GRAD_LAYOUTS[id(spec)] = res
+    return res
+
+
+def _grad_layout(spec):
     from .engine import layer_slots
     out, total = [], 0
     for _, _, layer in layer_slots(spec):
@@ -125,18 +138,8 @@ def _mp_backward(tape, x, edge_index, edge_attr, params, config, training, seed,
     if not training:
         prep.model.dropout_enc = prep.model.dropout_upd_edge = prep.model.dropout_upd_node = 0.0
     dev = prep.dev
-    layout, total = grad_layout(spec)
+    _, total = grad_layout(spec)                          # == mtmc_mpn_grad_layout (tests/test_torch_ops_registration.py)
     flat = torch.empty(total, dtype=torch.float32, device=dev)
-    base = flat.data_ptr()
-    grads = _lib.Model()
-    it = iter(layout)
-    from .engine import layer_slots
-    for slot, idx, layer in layer_slots(spec):
-        dst = getattr(grads, slot) if idx is None else getattr(grads, slot)[idx]
-        dst.weight, dst.bias = base + 4 * next(it)[0], base + 4 * next(it)[0]
-        if layer.bn_slot is not None:
-            dst.gamma, dst.beta = base + 4 * next(it)[0], base + 4 * next(it)[0]
-        dst.in_dim, dst.out_dim = layer.in_dim, layer.out_dim
     dx = torch.empty((prep.n, spec.enc_node[0].in_dim), device=dev) if need_x else flat.new_empty(0)
     dattr = torch.empty((prep.e, spec.enc_edge[0].in_dim), device=dev) if need_attr else flat.new_empty(0)
     dl = d_logits.contiguous().float() if d_logits is not None else None
@@ -147,10 +150,9 @@ def _mp_backward(tape, x, edge_index, edge_attr, params, config, training, seed,
                                              for i in range(n_steps)])
     with torch.cuda.device(dev):
         prep.call.stream = _stream(dev)
-        _lib.check(eng.lib.mtmc_mpn_backward_steps(
+        _lib.check(eng.lib.mtmc_mpn_backward_flat(
             C.byref(prep.model), C.byref(prep.call), steps, dh.data_ptr() if dh is not None else None,
-            C.byref(grads), flat.data_ptr(), flat.numel() * 4,
-            dx.data_ptr() if need_x else None, dattr.data_ptr() if need_attr else None))
+            flat.data_ptr(), flat.numel(), dx.data_ptr() if need_x else None, dattr.data_ptr() if need_attr else None))
     return flat, dx, dattr
 
 

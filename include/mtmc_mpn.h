@@ -184,6 +184,14 @@ int32_t mtmc_mpn_backward(const mtmc_mpn_model* model, const mtmc_mpn_call* call
 int32_t mtmc_mpn_backward_steps(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
                                 const float* const* d_logits_steps, const float* d_h, const mtmc_mpn_model* grads,
                                 void* grads_flat, size_t grads_flat_bytes, float* d_x, float* d_edge_attr);
+/* The same with the gradient carving done by the library: `flat` receives every parameter gradient in struct order
+ * (node encoder layers, edge encoder, edge update, node update, classifier; weight, bias, then gamma, beta where the layer
+ * has a BatchNorm), each piece on a 64-float boundary; mtmc_mpn_grad_layout writes the piece offsets (in floats, up to
+ * max_offsets of them) and returns the total length.  One allocation and no second pointer struct per call. */
+int64_t mtmc_mpn_grad_layout(const mtmc_mpn_model* model, int64_t* offsets, int32_t max_offsets);
+int32_t mtmc_mpn_backward_flat(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
+                               const float* const* d_logits_steps, const float* d_h, float* flat, int64_t flat_floats,
+                               float* d_x, float* d_edge_attr);
 int32_t mtmc_mpn_run_phase(const mtmc_mpn_model* model, const mtmc_mpn_call* call, int32_t phase, int32_t arg);
 
 /* out[dim_size, C] (fp32) <- scatter of src[E, C] by index[E] along dim 0; rows nobody writes are 0.

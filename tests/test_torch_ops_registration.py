@@ -55,6 +55,18 @@ def test_shape_inference_under_fake_tensors():
         assert v.shape == (50, 32) and a.dtype == torch.int64
 
 
+def test_python_and_c_agree_on_the_gradient_layout():
+    import ctypes as C
+    from mtmc_mpn import _lib
+    m, key = _model()
+    eng = engine.ForwardEngine(m)
+    model = eng.model_struct(torch.device("cpu"))           # pointers are never dereferenced by the layout query
+    off = (C.c_int64 * 64)()
+    total = _lib.load().mtmc_mpn_grad_layout(C.byref(model), off, 64)
+    layout, py_total = torch_ops.grad_layout(m.spec)
+    assert total == py_total and [o for o, _, _ in layout] == list(off)[:len(layout)]
+
+
 def test_gradient_layout_covers_every_parameter_once():
     m, key = _model()
     layout, total = torch_ops.grad_layout(m.spec)
