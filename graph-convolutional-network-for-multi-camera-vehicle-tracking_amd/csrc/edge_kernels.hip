@@ -134,27 +134,31 @@ __device__ __forceinline__ void load_edge_upd_weights(const RoundParams& p, Edge
   for (int k = 0; k < 4; ++k) {
     w.b[k] = p.ue_b[k];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) w.w[k][j] = j < nin ? p.ue_w[k * p.ue_ld + p.ue_eoff + j] : 0.f;
+    for (int j = 0; j < 8; ++j) w.w[k][j] = j < nin ? p.ue_w[k * p.ue_ld + p.ue_eoff + j] : 0.f;   // (dead columns fold away per MODE)
   }
 }
 
 struct PrevAffine { float s[4], t[4]; };   // BatchNorm affine of the previous round's z1 (lazy e')
 
+// MODE 0: a later round without reattached edges (no attribute loads, no edge-encoder arithmetic, 4 x 4 weights: the
+// general body's scalar operands do not fit the SGPR file -- 171 spills); bit 0: first round, bit 1: reattach_initial_edges
+template <int MODE>
 __device__ __forceinline__ void edge_z1(const RoundParams& p, const EdgeEncAffine& af, const EdgeUpdWeights& w,
                                         const PrevAffine& pa, int64_t e, int& r, float (&z)[4]) {
+  constexpr bool first_round = (MODE & 1) != 0, reattach = (MODE & 2) != 0;
   r = p.row32[e];
   const int c = p.col32[e];
   // P = [Pr: N x 4 | Pc: N x 4]: the randomly gathered half is a compact 16 B/node table (four nodes per 64-byte sector)
   const float4 pr = *reinterpret_cast<const float4*>(p.P + (int64_t)r * 4);
   const float4 pc = *reinterpret_cast<const float4*>(p.P + ((int64_t)p.n_nodes + c) * 4);
   float e0[4] = {0, 0, 0, 0}, ep[4];
-  if (p.first_round || p.reattach_edges) {
+  if (first_round || reattach) {
     float a0, a1, u[4];
     load_attr(p.attr, p.enc.fe, e, a0, a1);
     edge_enc_hidden(p.enc, af, e, a0, a1, u);
     edge_enc_out(p.enc, af, e, u, e0);
   }
-  if (p.first_round) {
+  if (first_round) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) ep[j] = e0[j];
   } else {
@@ -169,7 +173,7 @@ __device__ __forceinline__ void edge_z1(const RoundParams& p, const EdgeEncAffin
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     float acc = prv[k] + pcv[k] + w.b[k];
-    if (p.reattach_edges) {
+    if (reattach) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc = fmaf(w.w[k][j], e0[j], acc);
 #pragma unroll
@@ -185,13 +189,13 @@ __device__ __forceinline__ void edge_z1(const RoundParams& p, const EdgeEncAffin
 // kEPT = edges per thread and loop trip in passes A/B: four independent load chains in flight on big graphs, one on
 // small ones, where filling the 256 CUs with waves matters more (pick_ept)
 
-template <int kEPT>
+template <int kEPT, int MODE>
 __global__ __launch_bounds__(256) void pass_a_kernel(RoundParams p) {
   __shared__ EdgeEncAffine af;
   __shared__ double red[8 * 4];
   __shared__ PrevAffine pa_s;
-  if (p.first_round || p.reattach_edges) edge_enc_affine_load(p.enc, &af);
-  if (p.lazy_e && !p.first_round) {
+  if (MODE != 0) edge_enc_affine_load(p.enc, &af);
+  if (p.lazy_e && !(MODE & 1)) {
     stat_gather(p.prev_stats + kRoundZ1Off, 8, kZ1Stride, red);
     __syncthreads();
     if (threadIdx.x < 4)
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256) void pass_a_kernel(RoundParams p) {
       const int64_t e = base + i * 256;
       int r;
       if (e < p.n_edges) {
-        edge_z1(p, af, w, pa, e, r, z[i]);
+        edge_z1<MODE>(p, af, w, pa, e, r, z[i]);
         // the random 16-byte P[col] gather is what bounds this pass (one cache line per lane): do it once and
         // hand z1 to pass B through memory instead of gathering again there
         reinterpret_cast<float4*>(p.e_buf)[e] = make_float4(z[i][0], z[i][1], z[i][2], z[i][3]);
@@ -783,10 +787,20 @@ void launch_enc2(const EdgeEncParams& enc, const float* attr, int64_t n_edges, d
   hipLaunchKernelGGL(enc2_kernel, dim3(edge_grid(n_edges, 256)), dim3(256), 0, s, enc, attr, n_edges, e_total,
                      stat_enc2);
 }
-void launch_pass_a(const RoundParams& p, hipStream_t s) {
+template <int MODE>
+static void launch_pass_a_mode(const RoundParams& p, hipStream_t s) {
+  // (edges per thread 1/2/4/8 x grid caps 1536..16384 swept at config 4: 0.45-0.51 ms for the three launches, flat)
   switch (pick_ept(p.n_edges)) {
-    case 1: hipLaunchKernelGGL(pass_a_kernel<1>, dim3(edge_grid(p.n_edges, 256)), dim3(256), 0, s, p); break;
-    default: hipLaunchKernelGGL(pass_a_kernel<4>, dim3(edge_grid(p.n_edges, 1024)), dim3(256), 0, s, p);
+    case 1: hipLaunchKernelGGL((pass_a_kernel<1, MODE>), dim3(edge_grid(p.n_edges, 256)), dim3(256), 0, s, p); break;
+    default: hipLaunchKernelGGL((pass_a_kernel<4, MODE>), dim3(edge_grid(p.n_edges, 1024)), dim3(256), 0, s, p);
+  }
+}
+void launch_pass_a(const RoundParams& p, hipStream_t s) {
+  switch ((p.first_round ? 1 : 0) | (p.reattach_edges ? 2 : 0)) {
+    case 0: launch_pass_a_mode<0>(p, s); break;
+    case 1: launch_pass_a_mode<1>(p, s); break;
+    case 2: launch_pass_a_mode<2>(p, s); break;
+    default: launch_pass_a_mode<3>(p, s);
   }
 }
 void launch_pass_b(const RoundParams& p, hipStream_t s) {
