@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # fp32-input MFMA dense peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # bf16 MFMA dense peak; the split kernel spends 6 bf16 products per fp32 product
 
-PHASE_NAMES = {_lib.PH_BEGIN: "memset+prep_kernel", _lib.PH_EDGE_ENC: "enc2_kernel", _lib.PH_NODE_ENC: "gemm_bn_kernel",
+PHASE_NAMES = {_lib.PH_BEGIN: "memset+prep_kernel(+split_rows_kernel)", _lib.PH_EDGE_ENC: "enc2_kernel", _lib.PH_NODE_ENC: "gemm_bn_kernel",
                _lib.PH_NODE_COMBINE: "combine_stats_kernel",
                _lib.PH_NODE_H0: "bn_relu_rows_kernel", _lib.PH_ROUND_PROJ: "node_proj_kernel",
                _lib.PH_ROUND_A: "pass_a_kernel", _lib.PH_ROUND_B: "pass_b_kernel", _lib.PH_ROUND_STAT: "node_stat_kernel",
@@ -101,13 +101,17 @@ def pmc_traffic(workload, kernel):
     return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0
 
 
-def encoder_kernel(n_rows, layer):
-    """Which GEMM kernel csrc/gemm_bn.hip:gemm_plan picks for an encoder layer (mirrors its rule)."""
+def encoder_kernel(n_rows, layer, idx=None):
+    """Which GEMM kernel csrc/gemm_bn.hip:gemm_plan / csrc/gemm_presplit.hip:presplit_layer0 pick for an encoder layer
+    (mirrors their rules)."""
     big = ((n_rows + 127) // 128) * ((layer.out_dim + 127) // 128) >= 256 and layer.out_dim >= 128
     if os.environ.get("MTMC_GEMM_FP32"):
         return "gemm_bn_kernel"
     if os.environ.get("MTMC_GEMM_NO_F16"):
         return "gemm_bn_bf16x6_kernel" if big else "gemm_bn_kernel"
+    if idx == 0 and big and n_rows >= 4096 and layer.in_dim % 64 == 0 and layer.in_dim <= 2048 \
+            and not os.environ.get("MTMC_GEMM_NO_PRESPLIT"):
+        return "gemm_f16p_kernel"          # layer 0 of many-row graphs: pre-split operands (+ split_rows_kernel in PH_BEGIN)
     return "gemm_bn_f16x3_kernel"
 
 
@@ -299,7 +303,7 @@ def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
     # dominant kernel = the kernel NAME with the largest summed time (all its launches in a step, the same
     # granularity as a rocprofv3 --stats row); phases that launched nothing (un-split combine) are skipped
     def kernel_of(ph, arg):
-        return encoder_kernel(n, spec.enc_node[arg]) if ph == _lib.PH_NODE_ENC else PHASE_NAMES[ph]
+        return encoder_kernel(n, spec.enc_node[arg], arg) if ph == _lib.PH_NODE_ENC else PHASE_NAMES[ph]
     by_kind = {}
     for (ph, arg), t in zip(seq, ms):
         if ph == _lib.PH_NODE_COMBINE and t < 2e-3:
@@ -312,7 +316,7 @@ def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
     bound = kinds[0][0]
     work = sum(w for _, w in kinds) / len(kinds)
     peak_note = None
-    if bound == "mfma" and dom_key == "gemm_bn_f16x3_kernel":
+    if bound == "mfma" and dom_key in ("gemm_bn_f16x3_kernel", "gemm_f16p_kernel"):
         achieved, peak, unit = work / (avg_ms * 1e-3) / 1e12, MFMA_BF16_PEAK_TFLOPS / 3.0, "TFLOP/s"
         peak_note = ("algorithmic fp32 flops (2*M*N*K) against the fp16 dense MFMA peak (= the bf16 one) / 3: the kernel "
                      "reaches fp32 accuracy with three fp16 products per fp32 product")

@@ -37,6 +37,7 @@ struct Layout {
   bool training;
   std::vector<size_t> z_tr, e_tr, h_tr;       // per round: z1 [E][4], e' [E][4], aggregated h [N][32]
   std::vector<size_t> P_tr, Q_tr;             // per round: the node projections [2][N][4], [N][32]
+  size_t xh, inv_a, wh, inv_w; bool presplit0;   // layer 0 on pre-split operands (many-row graphs): fp16 planes + row scales
   size_t g_e[2], g_e0, g_h[2], g_h0, g_P, g_Q, g_de2, g_arg;   // gradients wrt e_r, e0, h_r, h0, P, Q; A^T dz2 [E][4]
   size_t bst;                                  // f64[2L+1][kStatRep][kBwdStride] backward statistics blocks
   size_t bwd_zero, bwd_zero_end;               // the range the backward clears with one memset
@@ -117,6 +118,16 @@ inline void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* l
     if (need > slab) slab = need;
   }
   lo->slab = take(slab);
+  // Layer 0 of a many-row graph runs on operands split ONCE into fp16 pairs (gemm_presplit.hip): planes of x [2][N][K]
+  // and of W0 [2][out][K] plus one power-of-two scale per row.  An x-sized region; eval mode only.
+  lo->presplit0 = !training && mtmc::presplit_layer0(N, m->enc_node[0].in_dim, m->enc_node[0].out_dim);
+  if (lo->presplit0) {
+    const size_t K0 = m->enc_node[0].in_dim, O0 = m->enc_node[0].out_dim;
+    lo->xh = take((size_t)2 * N * K0 * sizeof(uint16_t));
+    lo->inv_a = take((size_t)N * sizeof(float));
+    lo->wh = take((size_t)2 * O0 * K0 * sizeof(uint16_t));
+    lo->inv_w = take(O0 * sizeof(float));
+  }
   if (training) {
     for (int r = 0; r < L; ++r) {
       lo->z_tr.push_back(take((size_t)E * 4 * sizeof(float)));
@@ -275,6 +286,11 @@ inline mtmc::RoundParams round_params(const Ctx& x, int r) {
   return p;
 }
 
+// layer 0 on pre-split operands: the layout has the planes (whole graph many-row) AND this call's rows are many too
+inline bool use_presplit0(const Ctx& x) {
+  return x.lo.presplit0 && mtmc::presplit_layer0(x.c->node_hi - x.c->node_lo, x.m->enc_node[0].in_dim, x.m->enc_node[0].out_dim);
+}
+
 enum { kPhMemset = -1, kPhPrep = -2 };   // the two halves of MTMC_PH_BEGIN, for the forked forward
 
 inline const int* scale_deg(const Ctx& x) {   // the degree mean aggregation divides by
@@ -302,13 +318,20 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
         // operand |.|max values of the node encoder ride along (this rank's rows of x; every layer's weights)
         unsigned* amax = x.at<unsigned>(x.lo.amax);
         p.n_jobs = 0;
+        const bool pre0 = use_presplit0(x);
         if (c->node_hi > c->node_lo) {
-          p.jobs[p.n_jobs++] = {c->x, c->node_hi - c->node_lo, m->enc_node[0].in_dim, c->x_row_stride, amax, 0, 0};
-          for (int l = 0; l < m->n_enc_layers; ++l)
+          if (!pre0) p.jobs[p.n_jobs++] = {c->x, c->node_hi - c->node_lo, m->enc_node[0].in_dim, c->x_row_stride, amax, 0, 0};
+          for (int l = pre0 ? 1 : 0; l < m->n_enc_layers; ++l)
             p.jobs[p.n_jobs++] = {m->enc_node[l].weight, m->enc_node[l].out_dim, m->enc_node[l].in_dim,
                                   m->enc_node[l].in_dim, amax + (1 + l) * mtmc::kAmaxRep, 0, 0};
         }
         mtmc::launch_prep(p, s);
+        if (pre0) {     // instead of the |.|max of x and W0: their fp16 planes and row scales (one pass over each)
+          mtmc::launch_split_rows(c->x, c->x_row_stride, c->node_hi - c->node_lo, m->enc_node[0].in_dim, x.at<void>(x.lo.xh),
+                                  x.at<float>(x.lo.inv_a), s);
+          mtmc::launch_split_rows(m->enc_node[0].weight, m->enc_node[0].in_dim, m->enc_node[0].out_dim,
+                                  m->enc_node[0].in_dim, x.at<void>(x.lo.wh), x.at<float>(x.lo.inv_w), s);
+        }
       }
       break;
     }
@@ -322,6 +345,18 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
       const int64_t rows = c->node_hi - c->node_lo;
       if (rows == 0) break;
       const mtmc_layer& Lr = m->enc_node[arg];
+      if (arg == 0 && use_presplit0(x)) {
+        if (phase == MTMC_PH_NODE_COMBINE) break;                // never split along K
+        mtmc::SplitGemmParams q;
+        q.Ah = x.at<_Float16>(x.lo.xh); q.inv_a = x.at<float>(x.lo.inv_a);
+        q.Wh = x.at<_Float16>(x.lo.wh); q.inv_w = x.at<float>(x.lo.inv_w);
+        q.bias = Lr.bias; q.Y = x.at<float>(x.lo.Y[0]); q.ldy = Lr.out_dim;
+        q.stats_out = x.at<double>(x.lo.stat_enc_layer[0]);
+        q.amax_y = x.at<unsigned>(x.lo.amax) + (1 + MTMC_MAX_ENC_LAYERS) * mtmc::kAmaxRep;
+        q.M = rows; q.K = Lr.in_dim; q.Nout = Lr.out_dim;
+        if (mtmc::launch_gemm_presplit(q, s, 0) != 0) return fail(MTMC_E_ARG, "encoder layer 0: unsupported pre-split shape");
+        break;
+      }
       mtmc::GemmParams g;
       if (arg == 0) {
         g.A = c->x; g.lda = c->x_row_stride; g.stats_in = nullptr; g.gamma_in = nullptr; g.beta_in = nullptr;

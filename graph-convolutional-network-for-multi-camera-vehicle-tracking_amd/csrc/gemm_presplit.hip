@@ -1,7 +1,8 @@
-// EXPERIMENTAL (not on the forward path; reachable through mtmc_linear_presplit_raw, tools/presplit_time.py and
-// tests/test_gpu_gemm_presplit.py): the first encoder layer of many-row graphs on PRE-SPLIT operands.  Measured and
-// discussed in DESIGN.md 8: 1.28 ms against 1.45 ms for the in-loop kernel at 100k rows, which the 0.28 ms split
-// pass and an x-sized workspace nearly cancel; kept as the base of the counted-vmcnt pipeline that is the way up.
+// First node-encoder layer of MANY-ROW graphs on PRE-SPLIT operands (reference models/mlp.py:15-27 via models/mpn.py:168;
+// dispatch: presplit_layer0 -- >= 4096 rows of a 128x128-tile plan, K <= 2048): 1.28 ms against 1.45 ms for the in-loop
+// kernel at 100k rows, and the split pass (0.28 ms) replaces the |.|max pass over x (0.14 ms) that kernel needs; per-row
+// power-of-two scales instead of one per tensor.  Variants other than the default (tile shapes, counted-vmcnt pipelines,
+// the mid-barrier kernel) stay reachable through mtmc_linear_presplit_raw for A/B (tools/presplit_time.py).
 //
 // gemm_bn_f16x3_kernel splits every fp32 operand element into its two fp16 pieces inside the k-loop: an A element
 // Nout/128 times, a W element M/128 times, through VGPRs and ds_write (≈ 80 B/clk/CU).  For the one layer that
@@ -12,6 +13,8 @@
 //                       no VGPRs, no ds_write), three products a1w1 + a1w2 + a2w1, scales undone per row / column
 // Same representation error bound as the in-loop split (22 mantissa bits per operand); per-row scales only tighten it.
 #include <hip/hip_runtime.h>
+
+#include <stdlib.h>
 
 #include "common.h"
 #include "kernels.h"
@@ -459,6 +462,12 @@ static void launch_variant(const SplitGemmParams& p, hipStream_t s) {
     attr_set = true;
   }
   hipLaunchKernelGGL((gemm_f16p_kernel<BT, BK, NBUF, MINB>), dim3(grid), dim3(BT * 2), lds, s, p, tiles_m, tiles_n);
+}
+
+bool presplit_layer0(int64_t rows, int K, int Nout) {
+  static const bool off = getenv("MTMC_GEMM_NO_PRESPLIT") != nullptr || getenv("MTMC_GEMM_FP32") != nullptr || getenv("MTMC_GEMM_NO_F16") != nullptr;
+  int sk;
+  return !off && K % 64 == 0 && K <= 2048 && rows >= 4096 && gemm_plan(rows, K, Nout, &sk) == 2;
 }
 
 int launch_gemm_presplit(const SplitGemmParams& p, hipStream_t s, int variant) {
