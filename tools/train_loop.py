@@ -59,3 +59,4 @@ parts = [0.0] * 4
 for _ in range(iters):
     step(parts)
 print("synchronised split, ms: forward %.3f  loss %.3f  backward %.3f  optimizer %.3f" % tuple(p / iters * 1e3 for p in parts))
+print(f"steps profiled: {5 + 2 * iters}")
