@@ -809,10 +809,13 @@ void launch_combine(const GemmParams& p, hipStream_t s) {
 
 // 0: MFMA kernel not applicable; 1: 64x64 tiles; 2: 128x128 tiles.  *split_k > 1 only for few-row problems,
 // where one block per output tile would leave most of the 256 CUs idle and serialise the whole K loop.
-int gemm_plan(int64_t M, int K, int Nout, int* split_k) {
+// K > 6144 is only a limit for layers with an input BatchNorm under the fp32 / bf16 kernels (their whole input affine
+// sits in LDS); the fp16 kernel chunks it, and a product without an input affine (the weight-gradient GEMM of the
+// backward reduces over the node rows: K = N) has none.
+int gemm_plan(int64_t M, int K, int Nout, int* split_k, bool long_k_ok) {
   constexpr int BK = 64;
   *split_k = 1;
-  if (K % 32 != 0 || K > 6144) return 0;
+  if (K % 32 != 0 || (K > 6144 && !long_k_ok)) return 0;
   const int64_t big_tiles = ((M + 127) / 128) * ((Nout + 127) / 128);
   if (big_tiles >= 256 && Nout >= 128) return 2;   // one 128x128 tile per CU or more (fp16 kernel: 256 beats 512 at M = 6000)
   const int64_t tiles = ((M + 63) / 64) * ((Nout + 63) / 64);
@@ -826,7 +829,10 @@ int gemm_plan(int64_t M, int K, int Nout, int* split_k) {
 // which: 1 = the GEMM only, 2 = the split-K combine only (no-op for un-split layers), 3 = both
 int launch_gemm_bn(const GemmParams& p, hipStream_t s, int which) {
   if (p.M < 1 || p.Nout < 1 || p.K < 1) return MTMC_E_ARG;
-  if (p.K % 32 != 0 || p.K > 6144 || (p.lda % 4) != 0 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) {
+  static const bool fp32_only_env = getenv("MTMC_GEMM_FP32") != nullptr, no_f16_env = getenv("MTMC_GEMM_NO_F16") != nullptr;
+  const bool f16_ok = p.amax_a && p.amax_w && !fp32_only_env && !no_f16_env;
+  const bool long_k_ok = f16_ok;          // the fp16 kernel keeps at most kAffChunk affine columns in LDS at a time
+  if (p.K % 32 != 0 || (p.K > 6144 && !long_k_ok) || (p.lda % 4) != 0 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) {
     if (p.stats_in != nullptr || p.Nout > 2048) return MTMC_E_ARG;
     if (!(which & 1)) return MTMC_OK;
     const int64_t blocks = (p.M * p.Nout + 255) / 256;
@@ -836,7 +842,7 @@ int launch_gemm_bn(const GemmParams& p, hipStream_t s, int which) {
   }
   GemmParams q = p;
   int sk;
-  const int cfg = gemm_plan(p.M, p.K, p.Nout, &sk);
+  const int cfg = gemm_plan(p.M, p.K, p.Nout, &sk, long_k_ok);
   q.split_k = (p.slab != nullptr) ? sk : 1;
   if (which & 1) {
     static const bool fp32_only = getenv("MTMC_GEMM_FP32") != nullptr;

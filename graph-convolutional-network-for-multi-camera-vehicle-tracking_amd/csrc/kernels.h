@@ -126,7 +126,7 @@ void launch_bn_relu_rows(const float* Y, int64_t ldy, int64_t rows, int dim, con
 void launch_h_final(const float* src, const int* deg, int mean, int64_t n_nodes, float* dst, hipStream_t s);
 
 int launch_gemm_bn(const GemmParams& p, hipStream_t s, int which = 3);   // returns 0 or MTMC_E_ARG
-int gemm_plan(int64_t M, int K, int Nout, int* split_k);
+int gemm_plan(int64_t M, int K, int Nout, int* split_k, bool long_k_ok = false);
 
 void launch_scatter(const float* src, const int64_t* index, int64_t n_src, int64_t n_cols, int64_t dim_size,
                     float* out, float* count, int64_t* arg_out, int mode, hipStream_t s);
