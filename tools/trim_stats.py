@@ -8,8 +8,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 keep, other = [], {"Calls": 0, "TotalDurationNs": 0.0}
 for r in rows:
     name = r["Name"]
-    if "mtmc::" in name:
-        r["Name"] = name.split("(")[0].replace("void ", "")[:100]
+    if "mtmc::" in name or "_ZN4mtmc" in name:
+        r["Name"] = ("mtmc::split_rows_kernel" if "split_rows_kernel" in name else name.split("(")[0].replace("void ", ""))[:100]
         keep.append(r)
     else:
         other["Calls"] += int(r["Calls"])
