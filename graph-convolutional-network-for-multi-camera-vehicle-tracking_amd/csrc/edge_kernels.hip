@@ -397,7 +397,7 @@ __global__ __launch_bounds__(kTileC) void pass_c_kernel(RoundParams p) {
   __shared__ double st[10 + 64];           // e' second moments (10) | z2 sums (32) | z2 sums of squares (32)
   const int k = threadIdx.x & 31;          // channel
   const int hw = threadIdx.x >> 5;         // half-wave
-  if (p.mfma_c && p.flags[0] == 0) return; // row-sorted list: pass_c_mfma_kernel, launched just before, did this round
+  if (p.mfma_c == 1 && p.flags[0] == 0) return; // row-sorted list: pass_c_mfma_kernel, launched just before, did this round
   const int64_t n_tiles = (p.n_edges + kTileC - 1) / kTileC;
   int64_t tile = blockIdx.x;
   // a tile's operands do not depend on the statistics: fetch the first one before waiting for those
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: spans, chunks, rows stay scalar
   const int k = lane & 31, hi = lane >> 5;
-  if (p.flags[0] != 0) return;                               // unsorted rows: pass_c_kernel does this round (block-uniform)
+  if (p.mfma_c == 1 && p.flags[0] != 0) return;              // unsorted rows: pass_c_kernel does this round (block-uniform)
   stat_gather2(p.stats + kRoundMOff + 4, 10, kMStride, p.stats + kRoundZ2Off, 64, kZ2Stride, st);
   __shared__ double st1[8];
   __shared__ float s1s[4], t1s[4];
@@ -712,6 +712,30 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
           f32x16c acc = {};
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(xy[g]), b0, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(zw[g]), b1, acc, 0, 0, 0);
+          // how many distinct rows?  Up to four take one masked pass each; a group that is all over the place (unsorted
+          // or low-degree stretch of the list) is cheaper per EDGE: every register adds its own edge's constant and goes
+          // to its row with one atomic (bounded cost, no run bookkeeping)
+          int n_rows = 0;
+          {
+            unsigned left = gm;
+            while (left != 0 && n_rows <= 4) {
+              const int r = __builtin_amdgcn_readfirstlane(__shfl(rw, 32 * g + __ffs(left) - 1, 64));
+              left &= ~((unsigned)(__ballot(rw == r) >> (32 * g)));
+              ++n_rows;
+            }
+          }
+          if (n_rows > 4) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int off = (i & 3) + 8 * (i >> 2) + 4 * hi;
+              const int r = __shfl(rw, 32 * g + off, 64);
+              if (r >= 0 && ((gm >> off) & 1u)) {
+                const float c0 = fmaf(sk, p.Q[(int64_t)r * kH + k], cb);
+                unsafeAtomicAdd(p.h_acc + (int64_t)r * kH + k, fmaxf(acc[i] + c0, 0.f));
+              }
+            }
+            continue;
+          }
           unsigned done = 0;
           while (done != gm) {                                   // one masked pass per distinct row of the group
             const int pos = __ffs(gm & ~done) - 1;
@@ -809,27 +833,33 @@ void launch_pass_b(const RoundParams& p, hipStream_t s) {
     default: hipLaunchKernelGGL(pass_b_kernel<4>, dim3(edge_grid(p.n_edges, 1024)), dim3(256), 0, s, p);
   }
 }
-// Many edges per node on a many-edge list: the matrix-core kernel (it returns at once when prep_kernel found the rows
-// unsorted, and pass_c_kernel, launched behind it, returns at once when they are sorted: sortedness is only known on
-// the device).  MTMC_PASS_C_WALK=1 keeps the walk everywhere (A/B).
-static bool use_mfma_c(const RoundParams& p) {
+// Many edges per node: the matrix-core kernel.  mfma_c = 1 (many-edge lists): it returns at once when prep_kernel found
+// the rows unsorted, and pass_c_kernel, launched behind it, returns at once when they are sorted (sortedness is only known
+// on the device).  mfma_c = 2 (few-edge lists, where a second launch would cost as much as the pass): the matrix-core
+// kernel alone, whatever the order -- it is correct for any order, groups that touch many rows just take one masked pass
+// per row.  MTMC_PASS_C_WALK=1 keeps the walk everywhere (A/B).
+static int use_mfma_c(const RoundParams& p) {
   static const bool off = getenv("MTMC_PASS_C_WALK") != nullptr;
-  return !off && p.agg != 2 && !p.det && !p.drop_n.on && p.n_edges > kSmallEdges && p.n_nodes > 0 &&
-         p.n_edges / p.n_nodes >= 24;
+  static const int64_t small_min = getenv("MTMC_PASS_C_SMALL_MIN") ? atoll(getenv("MTMC_PASS_C_SMALL_MIN")) : 32768;
+  if (off || p.agg == 2 || p.det || p.drop_n.on || p.n_nodes <= 0 || p.n_edges / p.n_nodes < 24) return 0;
+  if (p.n_edges > kSmallEdges) return 1;
+  return p.n_edges >= small_min ? 2 : 0;
 }
 
 void launch_pass_c(const RoundParams& p0, hipStream_t s) {
   RoundParams p = p0;
-  p.mfma_c = use_mfma_c(p) ? 1 : 0;
+  p.mfma_c = use_mfma_c(p);
   if (p.mfma_c) {
-    // a resident grid (the block prologue -- 74 replicated statistics, one BatchNorm affine per channel -- is paid once
-    // per block, so blocks live long) whose waves take short spans round-robin (balance: ~6 spans per wave at config 4)
-    static const int span_c = getenv("MTMC_PASS_C_SPAN") ? atoi(getenv("MTMC_PASS_C_SPAN")) : 8;
+    // many edges: a resident grid (the block prologue -- 74 replicated statistics, one BatchNorm affine per channel -- is
+    // paid once per block, so blocks live long) whose waves take short spans round-robin (~6 spans per wave at config 4);
+    // few edges: one 64-edge chunk per wave, as many waves as there are chunks
+    static const int span_env = getenv("MTMC_PASS_C_SPAN") ? atoi(getenv("MTMC_PASS_C_SPAN")) : 0;
     static const int max_blocks = getenv("MTMC_PASS_C_BLOCKS") ? atoi(getenv("MTMC_PASS_C_BLOCKS")) : 256 * 6;
+    const int span_c = span_env > 0 ? span_env : (p.mfma_c == 2 ? 1 : 8);
     const int64_t spans = ((p.n_edges + 63) / 64 + span_c - 1) / span_c, blocks = (spans + 3) / 4;
     hipLaunchKernelGGL(pass_c_mfma_kernel, dim3((int)(blocks > max_blocks ? max_blocks : blocks)), dim3(256), 0, s, p, span_c);
   }
-  hipLaunchKernelGGL(pass_c_kernel, dim3(edge_grid(p.n_edges, kTileC)), dim3(kTileC), 0, s, p);
+  if (p.mfma_c != 2) hipLaunchKernelGGL(pass_c_kernel, dim3(edge_grid(p.n_edges, kTileC)), dim3(kTileC), 0, s, p);
   if (p.det && p.agg != 2) {
     const int64_t blocks = (p.n_nodes + 7) / 8;
     hipLaunchKernelGGL(agg_fixup_kernel, dim3((int)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks))), dim3(256), 0, s, p);

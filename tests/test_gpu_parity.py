@@ -221,6 +221,29 @@ def test_mid_size_sorted_graph_against_oracle():
     assert (h.cpu().double() - oh64).abs().max().item() <= 1e-4 * max(1.0, oh64.abs().max().item())
 
 
+@pytest.mark.parametrize("n,e", [(1000, 40000), (900, 33000)])
+def test_unsorted_list_with_many_edges_per_node(n, e):
+    """Few-edge lists with >= 24 edges per node take the matrix-core pass C alone, whatever their order: on a randomly
+    ordered list every 32-edge group touches ~32 rows -- the per-edge fallback of pass_c_mfma_kernel -- and duplicates /
+    self-loops occur.  Against the fp64 oracle."""
+    from oracle import mpn_oracle
+    torch.manual_seed(0)
+    params = mtmc_mpn.default_params(num_enc_steps=3, num_class_steps=2)
+    m = mtmc_mpn.MOTMPNet(copy.deepcopy(params), None, ARCH).eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    d = graphs.random_graph(n, e, seed=5)
+    d.x = torch.nn.functional.normalize(d.x, p=2, dim=0)
+    with torch.no_grad():
+        ora64, oh64 = mpn_oracle.forward(sd, copy.deepcopy(params), ARCH, d.x, d.edge_index, d.edge_attr, dtype=torch.float64)
+        out, h = m.cuda()(to_gpu(d))
+    for i in range(2):
+        got = out["classified_edges"][i].cpu().double()
+        assert (got - ora64["classified_edges"][i]).abs().max().item() <= LOGIT_TOL
+        bad, _ = label_mismatches(got, ora64["classified_edges"][i])
+        assert bad == 0
+    assert (h.cpu().double() - oh64).abs().max().item() <= 1e-4 * max(1.0, oh64.abs().max().item())
+
+
 def _gpu_shard_worker(rank, world, port, case_name, out_dir):
     import os
     import torch.distributed as dist
