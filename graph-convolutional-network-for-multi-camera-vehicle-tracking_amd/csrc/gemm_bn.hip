@@ -674,7 +674,7 @@ __global__ __launch_bounds__(256) void gemm_bn_f16x3_kernel(GemmParams p, int ti
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is per device: remember it per (kernel, device), under a lock.
-static bool allow_big_lds(const void* fn, int bytes) {
+bool allow_big_lds(const void* fn, int bytes) {
   static std::mutex mu;
   static std::set<std::pair<const void*, int>> done;
   int dev = 0;

@@ -103,6 +103,8 @@ struct SplitGemmParams {
   int64_t M; int K; int Nout;
 };
 void launch_split_rows(const float* X, int64_t ld, int64_t rows, int K, void* H, float* inv, hipStream_t s);
+// hipFuncAttributeMaxDynamicSharedMemorySize, once per (kernel, device); false when HIP refuses (gemm_bn.hip)
+bool allow_big_lds(const void* fn, int bytes);
 bool presplit_layer0(int64_t rows, int K, int Nout);   // many rows, K % 64 == 0, K <= 2048, not disabled (MTMC_GEMM_NO_PRESPLIT)
 int launch_gemm_presplit(const SplitGemmParams& p, hipStream_t s, int variant = 0);   // 0 ok, 1 unsupported shape
 
