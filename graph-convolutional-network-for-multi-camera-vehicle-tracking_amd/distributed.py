@@ -82,8 +82,10 @@ class ShardedForward:
     """Runs one forward on this rank's shard.  `backend` is a ForwardEngine (HIP) or anything with the same
     five methods."""
 
-    def __init__(self, backend, spec, group=None):
-        self.backend, self.spec, self.group = backend, spec, group
+    def __init__(self, backend, spec, group=None, exchange_alone=False):
+        """exchange_alone: run the row exchanges also in a group of ONE rank (where they move nothing) -- a rehearsal of the
+        RCCL calls on a single-GPU box (tests/test_gpu_sharded_forward.py); off by default."""
+        self.backend, self.spec, self.group, self.exchange_alone = backend, spec, group, exchange_alone
 
     # collectives (in place on workspace views)
     def _sum(self, t):
@@ -96,7 +98,7 @@ class ShardedForward:
         """Every rank holds COMPLETE rows [lo_r, hi_r) of h (row-snapped shards of a row-sorted list): exchange them
         with one all-gather (half the bytes of the all-reduce they make unnecessary), padded to the longest range."""
         longest = max(hi - lo for lo, hi in row_ranges)
-        if longest == 0 or world == 1:
+        if longest == 0 or (world == 1 and not self.exchange_alone):
             return
         lo, hi = row_ranges[rank]
         send = h.new_empty((longest, h.shape[1]))      # the padding rows are never copied out
@@ -208,13 +210,13 @@ def row_ranges_of(edge_index_local, group=None):
 
 
 def sharded_forward(module, x_local, node_range, edge_index_local, edge_attr_local, n_edges_total, group=None,
-                    row_ranges=None, own_rows=False, replicate_h=True):
+                    row_ranges=None, own_rows=False, replicate_h=True, exchange_alone=False):
     """Convenience wrapper: one edge-partitioned forward of a (HIP-backed) MOTMPNet on this rank's shard.
     Returns ({'classified_edges': [local logits]}, h) with h replicated on every rank (unless replicate_h=False)."""
     from . import engine
     if module._engine is None:
         module._engine = engine.ForwardEngine(module)
-    logits, h = ShardedForward(module._engine, module.spec, group)(x_local, node_range, edge_index_local,
+    logits, h = ShardedForward(module._engine, module.spec, group, exchange_alone)(x_local, node_range, edge_index_local,
                                                                   edge_attr_local, n_edges_total, row_ranges, own_rows,
                                                                   replicate_h)
     return {"classified_edges": logits}, h

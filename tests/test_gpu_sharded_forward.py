@@ -37,7 +37,7 @@ def _case(agg):
     return d, p
 
 
-def _worker(rank, world, port, agg, snap, out_dir, own=False, backend="gloo"):
+def _worker(rank, world, port, agg, snap, out_dir, own=False, backend="gloo", alone=False):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import mtmc_mpn
@@ -65,7 +65,8 @@ def _worker(rank, world, port, agg, snap, out_dir, own=False, backend="gloo"):
             lo, hi = mdist.tile_rows(rr, n)[rank]
         with torch.no_grad():
             out, h = mdist.sharded_forward(model, d.x[lo:hi].contiguous().to(dev), (lo, hi, n), ei,
-                                           d.edge_attr[elo:ehi].contiguous().to(dev), e, row_ranges=rr, own_rows=own)
+                                           d.edge_attr[elo:ehi].contiguous().to(dev), e, row_ranges=rr, own_rows=own,
+                                           exchange_alone=alone)
         torch.cuda.synchronize()
         torch.save({"logits": [o.cpu() for o in out["classified_edges"]], "h": h.cpu(), "edges": (elo, ehi)},
                    os.path.join(out_dir, f"rank{rank}.pt"))
@@ -90,13 +91,22 @@ def test_sharded_forward_over_rccl_two_gpus(agg, snap, own, tmp_path):
     _run_and_compare(2, agg, snap, own, tmp_path, "nccl")
 
 
-def _run_and_compare(world, agg, snap, own, tmp_path, backend):
+@pytest.mark.parametrize("agg,snap,own", [("sum", False, False), ("mean", True, False), ("max", True, True),
+                                          ("sum+gaps", True, True)])
+def test_rccl_calls_rehearsed_in_a_group_of_one(agg, snap, own, tmp_path):
+    """Every RCCL call of distributed.py (all_reduce of the statistics blocks and of the node state, all_gather_into_tensor
+    of Pc / h0 / the final h, the device-side all-gather of row_ranges_of) issued for real on the one GPU this box has:
+    a group of one rank moves nothing, but dtypes, shapes, contiguity and stream order are what RCCL sees at any size."""
+    _run_and_compare(1, agg, snap, own, tmp_path, "nccl", alone=True)
+
+
+def _run_and_compare(world, agg, snap, own, tmp_path, backend, alone=False):
     import types
     import mtmc_mpn
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(world, port, agg, snap, str(tmp_path), own, backend), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, agg, snap, str(tmp_path), own, backend, alone), nprocs=world, join=True)
     parts = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt")) for r in range(world)]
     dev = torch.device("cuda:0")
     d, p = _case(agg)
