@@ -71,10 +71,17 @@ def algorithmic_bytes_forward(n, e, L, cs, f=2048):
 
 def pmc_round(workload):
     """The newest round whose counter summaries for this workload are committed under profiles/."""
-    for rnd in ("r02", "r01"):
+    for rnd in committed_rounds():
         if all(os.path.exists(os.path.join(ROOT, "profiles", f"{rnd}_{workload}_pmc_{c}.txt")) for c in ("FETCH_SIZE", "WRITE_SIZE")):
             return rnd
     return None
+
+
+def committed_rounds():
+    """Round prefixes (rNN) that have files under profiles/, newest first."""
+    import re
+    names = os.listdir(os.path.join(ROOT, "profiles")) if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+    return sorted({m.group(0) for m in (re.match(r"r\d\d", f) for f in names) if m}, reverse=True)
 
 
 def pmc_traffic(workload, kernel):
@@ -492,7 +499,7 @@ def run_training_step(device):
 def train_kernel_ms():
     """Kernel time of one training step from the newest committed rocprofv3 summary (tools/train_profile.sh)."""
     import csv
-    for rnd in ("r02", "r01"):
+    for rnd in committed_rounds():
         path = os.path.join(ROOT, "profiles", f"{rnd}_train_kernel_stats.csv")
         meta = os.path.join(ROOT, "profiles", f"{rnd}_train_kernel_stats.steps")
         if os.path.exists(path):
