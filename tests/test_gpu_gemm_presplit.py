@@ -73,3 +73,32 @@ def test_presplit_rejects_bad_shapes():
     W = torch.randn(8, 64, device="cuda")
     with pytest.raises(RuntimeError):
         _run(lib, A, W, b, 0, work=torch.empty(64, dtype=torch.uint8, device="cuda"))   # work too small
+
+
+@pytest.mark.parametrize("M,K", [(77, 64), (1030, 512), (4097, 2048)])
+def test_plane_layout_and_split_are_as_documented(M, K):
+    """The fp16 planes in `work` follow the layout csrc/gemm_presplit.hip documents (kPlaneKT note): the eight halves
+    k..k+7 of row r sit at ((k/32)*rows + r)*32 + 8*(((k%32)/8) ^ ((r>>2)&3)); h1 + h2 reproduce x * 2^(14-e) to 22 bits
+    and inv[r] = 2^(e-14) with 2^(e-1) <= max|row| < 2^e."""
+    from mtmc_mpn import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + K)
+    A = (torch.randn(M, K, generator=g) * torch.logspace(-3, 3, M).unsqueeze(1)).cuda()
+    A[M // 2] = 0.0                                              # a zero row: scale stays finite
+    W = torch.randn(40, K, generator=g).cuda()
+    _, _, _, work = _run(lib, A, W, torch.zeros(40, device="cuda"), 0)
+    planes = work[:M * K * 4].view(torch.float16).view(2, K // 32, M, 4, 8)      # [piece][k-tile][row][slot][8]
+    inv = work[M * K * 4:M * K * 4 + M * 4].view(torch.float32)
+    r = torch.arange(M, device="cuda")
+    slot = torch.arange(4, device="cuda").unsqueeze(0) ^ ((r >> 2) & 3).unsqueeze(1)          # [row][logical slot] -> stored slot
+    idx = slot.view(1, 1, M, 4, 1).expand(2, K // 32, M, 4, 8)
+    logical = torch.gather(planes, 3, idx)                       # [piece][k-tile][row][logical slot][8]
+    h = logical.permute(0, 2, 1, 3, 4).reshape(2, M, K).double()
+    rec = (h[0] + h[1]) * inv.double().unsqueeze(1)
+    amax = A.abs().amax(dim=1).double()
+    assert (rec - A.double()).abs().max().item() <= 0.0 + (amax * 2.0 ** -21).max().item()
+    assert ((rec - A.double()).abs() <= amax.unsqueeze(1) * 2.0 ** -21 + 1e-300).all()
+    live = amax > 0
+    e = torch.log2(inv.double()[live]) + 14
+    assert (e == e.round()).all()                                # powers of two
+    assert ((amax[live] < 2.0 ** e) & (amax[live] >= 2.0 ** (e - 1))).all()
