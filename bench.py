@@ -118,7 +118,7 @@ def encoder_kernel(n_rows, layer, idx=None):
         return "gemm_bn_bf16x6_kernel" if big else "gemm_bn_kernel"
     if idx == 0 and big and n_rows >= 4096 and layer.in_dim % 64 == 0 and layer.in_dim <= 2048 \
             and not os.environ.get("MTMC_GEMM_NO_PRESPLIT"):
-        return "gemm_f16p_mid_kernel"      # layer 0 of many-row graphs: pre-split operands (+ split_rows_kernel in PH_BEGIN)
+        return "gemm_f16p_m16_kernel"      # layer 0 of many-row graphs: pre-split operands (+ split_rows_kernel in PH_BEGIN)
     return "gemm_bn_f16x3_kernel"
 
 
@@ -323,7 +323,7 @@ def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
     bound = kinds[0][0]
     work = sum(w for _, w in kinds) / len(kinds)
     peak_note = None
-    if bound == "mfma" and dom_key in ("gemm_bn_f16x3_kernel", "gemm_f16p_mid_kernel"):
+    if bound == "mfma" and dom_key in ("gemm_bn_f16x3_kernel", "gemm_f16p_m16_kernel"):
         achieved, peak, unit = work / (avg_ms * 1e-3) / 1e12, MFMA_BF16_PEAK_TFLOPS / 3.0, "TFLOP/s"
         peak_note = ("algorithmic fp32 flops (2*M*N*K) against the fp16 dense MFMA peak (= the bf16 one) / 3: the kernel "
                      "reaches fp32 accuracy with three fp16 products per fp32 product")

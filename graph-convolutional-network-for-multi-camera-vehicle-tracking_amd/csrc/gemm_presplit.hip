@@ -1,15 +1,16 @@
 // First node-encoder layer of MANY-ROW graphs on PRE-SPLIT operands (reference models/mlp.py:15-27 via models/mpn.py:168;
-// dispatch: presplit_layer0 -- >= 4096 rows of a 128x128-tile plan, K <= 2048): 1.28 ms against 1.45 ms for the in-loop
-// kernel at 100k rows, and the split pass (0.28 ms) replaces the |.|max pass over x (0.14 ms) that kernel needs; per-row
-// power-of-two scales instead of one per tensor.  Variants other than the default (tile shapes, counted-vmcnt pipelines,
-// the mid-barrier kernel) stay reachable through mtmc_linear_presplit_raw for A/B (tools/presplit_time.py).
+// dispatch: presplit_layer0 -- >= 4096 rows of a 128x128-tile plan, K <= 2048): 1.10-1.15 ms against 1.45 ms for the
+// in-loop kernel at 100k rows, and the split pass (0.30 ms) replaces the |.|max pass over x (0.14 ms) that kernel
+// needs; per-row power-of-two scales instead of one per tensor.  The forward runs gemm_f16p_m16_kernel (variant 11); the
+// other variants (tile shapes, counted-vmcnt pipelines, the mid-barrier and ping-pong kernels, timing experiments) stay
+// reachable through mtmc_linear_presplit_raw for A/B (tools/presplit_time.py).
 //
 // gemm_bn_f16x3_kernel splits every fp32 operand element into its two fp16 pieces inside the k-loop: an A element
 // Nout/128 times, a W element M/128 times, through VGPRs and ds_write (≈ 80 B/clk/CU).  For the one layer that
 // dominates a many-row forward (x[M][2048] -> 1024, reference models/mlp.py:15-27 via models/mpn.py:168) the split is
 // taken out of the loop:
 //   split_rows_kernel   x -> (h1, h2) fp16 planes + one power-of-two scale per ROW (one pass: the row is in registers)
-//   gemm_f16p_kernel    plain fp16 MFMA GEMM on the planes, tiles brought in by LDS-DMA (global_load_lds_dwordx4:
+//   gemm_f16p_*_kernel  plain fp16 MFMA GEMM on the planes, tiles brought in by LDS-DMA (global_load_lds_dwordx4:
 //                       no VGPRs, no ds_write), three products a1w1 + a1w2 + a2w1, scales undone per row / column
 // Same representation error bound as the in-loop split (22 mantissa bits per operand); per-row scales only tighten it.
 #include <hip/hip_runtime.h>
@@ -530,6 +531,151 @@ __global__ __launch_bounds__(512, 1) void gemm_f16p_mid_kernel(SplitGemmParams p
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same 256 x 256 x 32 tile on v_mfma_f32_16x16x32_f16 (variant 11).  One instruction takes the whole k-tile
+// (K = 32) of a 16 x 16 output block: per flop it moves half the accumulator registers of the 32x32x16 form and twice the
+// operand registers, and the bare-loop probe (tools/hazard/mfma_probe.hip, bit 128) sustains 12 % more flops per second
+// with it at the socket's power cap, where this GEMM runs.  A wave's 128 x 64 share is 8 x 4 blocks of
+// 16 x 16 (32 accumulator quads = the same 128 registers); fragment reads: lane l takes row l % 16 of a 16-row block and
+// the 16-byte slot l / 16 of its 64-byte image row (the stored swizzle makes every 16-lane group conflict-free here
+// too); plain two-stage loop, the compiler places the reads.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512, 1) void gemm_f16p_m16_kernel(SplitGemmParams p, int tiles_m, int tiles_n) {
+  constexpr int BT = 256, BK = 32, NT = 512, ROWB = BK * 2, IMG = BT * ROWB, STAGE = 4 * IMG;
+  constexpr int SLOTS = BK / 8, RPI = NT / SLOTS, IPI = BT / RPI;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tm_idx = (slot / tiles_n) * 8 + xcd, tn_idx = slot % tiles_n;
+  if (tm_idx >= tiles_m) return;
+  const int64_t m0 = (int64_t)tm_idx * BT;
+  const int n0 = tn_idx * BT;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wid / 4, wn = wid % 4;
+
+  const int r0 = threadIdx.x / SLOTS, sp = threadIdx.x % SLOTS;
+  unsigned off_a[IPI], off_w[IPI];
+#pragma unroll
+  for (int j = 0; j < IPI; ++j) {
+    const int r = r0 + RPI * j;
+    const int64_t ar = m0 + r < p.M ? r : p.M - 1 - m0;
+    const int br = n0 + r < p.Nout ? r : p.Nout - 1 - n0;
+    off_a[j] = (unsigned)(ar * BK + sp * 8) * 2u;
+    off_w[j] = (unsigned)(br * BK + sp * 8) * 2u;
+  }
+  const unsigned lds0 = (unsigned)(size_t)smem;
+  const char* a_tile = reinterpret_cast<const char*>(p.Ah + m0 * BK);
+  const char* w_tile = reinterpret_cast<const char*>(p.Wh + (int64_t)n0 * BK);
+  const int64_t a_plane = p.M * (int64_t)p.K * 2, w_plane = (int64_t)p.Nout * p.K * 2;
+  const int64_t a_kt = p.M * BK * 2, w_kt = (int64_t)p.Nout * BK * 2;
+  auto issue = [&](int kt, int buf) {
+    const unsigned st = lds0 + buf * STAGE + wid * 1024;
+#pragma unroll
+    for (int im = 0; im < 4; ++im) {
+      const char* sb = (im < 2 ? a_tile : w_tile) + (im & 1 ? (im < 2 ? a_plane : w_plane) : 0) + kt * (im < 2 ? a_kt : w_kt);
+#pragma unroll
+      for (int j = 0; j < IPI; ++j) lds_dma16(sb, im < 2 ? off_a[j] : off_w[j], st + im * IMG + j * (NT * 16));
+    }
+  };
+
+  const int r16 = lane & 15, ks = lane >> 4;                       // fragment row inside a 16-row block, 8-half k group
+  const int so = (ks ^ ((r16 >> 2) & 3)) * 16;                     // the stored swizzle: slot ^ ((row >> 2) & 3)
+  const int a_row = (wm * 128 + r16) * ROWB + so, b_row = (wn * 64 + r16) * ROWB + so;
+
+  f32x4v acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  auto multiply = [&](int buf) {
+    const unsigned char* st = smem + buf * STAGE;
+    f16x8 b[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) b[j][q] = *reinterpret_cast<const f16x8*>(st + (2 + q) * IMG + b_row + j * 16 * ROWB);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      f16x8 a[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) a[q] = *reinterpret_cast<const f16x8*>(st + q * IMG + a_row + i * 16 * ROWB);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], b[j][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[j][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[j][0], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  const int nk = p.K / BK;
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of tile kt has landed
+    __syncthreads();                      // ... for every wave; stage (kt+1)&1 is free again
+    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    multiply(kt & 1);
+  }
+
+  // ---- epilogue: a lane holds, per 16 x 16 block, rows 4*(lane/16) .. +3 of column lane%16
+  __syncthreads();
+  double* colred = reinterpret_cast<double*>(smem);
+  float ymax = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int cl = wn * 64 + j * 16 + r16;
+    const int col = n0 + cl;
+    const bool cok = col < p.Nout;
+    const float bias = cok ? p.bias[col] : 0.f;
+    const float iw = cok ? p.inv_w[col] : 0.f;
+    double cs = 0, cq = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = m0 + wm * 128 + i * 16 + 4 * ks + r;
+        if (row < p.M && cok) {
+          const float y = fmaf(acc[i][j][r] * p.inv_a[row], iw, bias);
+          p.Y[row * p.ldy + col] = y;
+          ymax = fmaxf(ymax, fabsf(y));
+          cs += y;
+          cq += (double)y * y;
+        }
+      }
+    }
+    cs += __shfl_xor(cs, 16, 64);
+    cq += __shfl_xor(cq, 16, 64);
+    cs += __shfl_xor(cs, 32, 64);
+    cq += __shfl_xor(cq, 32, 64);
+    if (lane < 16) {
+      colred[(wm * 2 + 0) * BT + cl] = cs;
+      colred[(wm * 2 + 1) * BT + cl] = cq;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * BT; i += NT) {
+    const int which = i / BT, cl = i % BT, col = n0 + cl;
+    if (col < p.Nout && p.stats_out)
+      unsafeAtomicAdd(p.stats_out + which * p.Nout + col, colred[(0 * 2 + which) * BT + cl] + colred[(1 * 2 + which) * BT + cl]);
+  }
+  if (p.amax_y) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, off, 64));
+    __syncthreads();
+    float* wmax = reinterpret_cast<float*>(smem);
+    if (lane == 0) wmax[wid] = ymax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = wmax[0];
+#pragma unroll
+      for (int w = 1; w < NT / 64; ++w) m = fmaxf(m, wmax[w]);
+      atomicMax(p.amax_y + (blockIdx.x % kAmaxRep), __float_as_uint(m));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Ping-pong: the two waves of every SIMD alternate roles.  256 x 256 tile, BK = 32, two LDS stages, TWO barriers per
 // k-tile.  Waves 0-3 (rows 0-127) and waves 4-7 (rows 128-255) share the SIMDs pairwise; in every phase one wave of a
 // pair issues its whole k-tile of MFMAs (48, operands already in registers) while its partner reads ITS next k-tile of
@@ -721,6 +867,15 @@ static int launch_pp(const SplitGemmParams& p, hipStream_t s) {
   return MTMC_OK;
 }
 
+static int launch_m16(const SplitGemmParams& p, hipStream_t s) {
+  const int tiles_m = (int)((p.M + 255) / 256), tiles_n = (p.Nout + 255) / 256;
+  const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
+  const size_t lds = (size_t)2 * 4 * 256 * 32 * 2;
+  if (!allow_big_lds(reinterpret_cast<const void*>(gemm_f16p_m16_kernel), 160 * 1024)) return MTMC_E_HIP;
+  hipLaunchKernelGGL(gemm_f16p_m16_kernel, dim3(grid), dim3(512), lds, s, p, tiles_m, tiles_n);
+  return MTMC_OK;
+}
+
 static int launch_mid(const SplitGemmParams& p, hipStream_t s) {
   const int tiles_m = (int)((p.M + 255) / 256), tiles_n = (p.Nout + 255) / 256;
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
@@ -755,6 +910,7 @@ int launch_gemm_presplit(const SplitGemmParams& p, hipStream_t s, int variant) {
     case 4: return launch_variant<256, 32, 1, 1>(p, s);
     case 8: return launch_variant<128, 32, 3, 1>(p, s);       // counted-vmcnt pipeline, two k-tiles in flight
     case 9: return launch_mid(p, s);                          // mid-tile barrier, fragments double-buffered
+    case 11: return launch_m16(p, s);                         // 16x16x32 MFMAs, plain two-stage loop
     case 10: return launch_pp(p, s);                          // ping-pong: SIMD partners alternate MFMA / read roles
     // timing experiments, results are WRONG (DESIGN.md 3.1 quotes them; tools/presplit_time.py runs them):
     case 12: return launch_variant<256, 32, 2, 1, 2>(p, s);   // no MFMAs

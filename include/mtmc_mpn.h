@@ -221,8 +221,8 @@ int32_t mtmc_linear_raw(const float* A, int64_t lda, const float* W, const float
 /* The pre-split twin of mtmc_linear_raw (csrc/gemm_presplit.hip; what the forward runs for encoder layer 0 of graphs
  * with >= 4096 nodes): A and W are first split into fp16 pairs with one power-of-two scale per row, stored k-tile-major
  * (work: >= 4*M*K + 4*N*K + 4*(M+N) + 1024 bytes of device memory), then multiplied by a plain fp16 MFMA GEMM fed by
- * LDS-DMA.  K a multiple of 64, K <= 2048.  variant >= 0 picks the kernel (9: the one the forward uses; 0, 2, 3, 4, 8,
- * 10: alternates kept for A/B; 12-17: timing experiments); variant < 0 reuses the planes already in
+ * LDS-DMA.  K a multiple of 64, K <= 2048.  variant >= 0 picks the kernel (11: the one the forward uses; 0, 2, 3, 4, 8,
+ * 9, 10: alternates kept for A/B; 12-17: timing experiments); variant < 0 reuses the planes already in
  * `work` with variant -v-1. */
 int32_t mtmc_linear_presplit_raw(const float* A, int64_t lda, const float* W, const float* bias, float* Y, int64_t M,
                                  int32_t K, int32_t N, void* work, uint64_t work_bytes, uint32_t* scratch,

@@ -24,7 +24,7 @@ def _run(lib, A, W, b, variant, work=None):
 
 
 @pytest.mark.parametrize("shape", [(129, 64, 128), (300, 512, 130), (777, 2048, 1024), (1030, 1024, 520)])
-@pytest.mark.parametrize("variant", [0, 2, 3, 4, 8, 9, 10])
+@pytest.mark.parametrize("variant", [0, 2, 3, 4, 8, 9, 10, 11])
 def test_presplit_matches_float64(shape, variant):
     from mtmc_mpn import _lib
     lib = _lib.load()

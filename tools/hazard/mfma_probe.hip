@@ -18,6 +18,7 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define CK(x)                                                                 \
   do {                                                                        \
@@ -112,7 +113,20 @@ __global__ __launch_bounds__(512) void probe(const _Float16* __restrict__ src, f
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     if (MODE & 2) __builtin_amdgcn_s_barrier();
-    if (!(MODE & 16)) {
+    if (MODE & 128) {                                           // the same flops as 96 v_mfma_f32_16x16x32_f16 (16 passes... 8 clocks each x2)
+      f32x4* a4 = reinterpret_cast<f32x4*>(acc);                 // 32 accumulator tiles of 16x16
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              a4[(i * 2 + j) * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ks][i][pr == 2], fb[ks][j][pr == 1], a4[(i * 2 + j) * 4 + 0], 0, 0, 0);
+              a4[(i * 2 + j) * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ks][i][pr != 2], fb[ks][j][pr == 1], a4[(i * 2 + j) * 4 + 1], 0, 0, 0);
+            }
+    } else if (!(MODE & 16)) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -163,7 +177,7 @@ static void run(const _Float16* src, float* out, long src_elems, int iters) {
   const double waves = (double)grid * threads / 64;
   const double flop = waves * iters * 48.0 * 32768.0;
   const double dma = (MODE & 4) ? waves * iters * 8.0 * 1024.0 : 0.0;
-  printf("mode %2d (%s%s%s%s%s%s): %8.3f ms", MODE, (MODE & 16) ? "no-mfma " : "mfma ", (MODE & 1) ? ((MODE & 32) ? "ds_read(gemm pattern) " : "ds_read ") : "",
+  printf("mode %2d (%s%s%s%s%s%s): %8.3f ms", MODE, (MODE & 16) ? "no-mfma " : ((MODE & 128) ? "mfma16x16x32 " : "mfma "), (MODE & 1) ? ((MODE & 32) ? "ds_read(gemm pattern) " : "ds_read ") : "",
          (MODE & 2) ? "barrier " : "", (MODE & 4) ? "dma " : "", (MODE & 64) ? "wide-data " : "", (MODE & 8) ? "1wave/simd" : "2waves/simd", best);
   if (!(MODE & 16)) printf("  %7.1f TFLOP/s fp16", flop / best * 1e-9);
   if (dma > 0) printf("  DMA %6.2f TB/s", dma / best * 1e-9);
@@ -195,6 +209,8 @@ int main() {
   run<33>(src, out, elems, iters);
   run<35>(src, out, elems, iters);
   run<99>(src, out, elems, iters);
+  run<99 + 128>(src, out, elems, iters);
+  run<35 + 128>(src, out, elems, iters);
   run<20>(src, out, elems, iters);
   run<23>(src, out, elems, iters);
   return 0;

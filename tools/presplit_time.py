@@ -31,7 +31,7 @@ def check(M, K, N):
     scr = torch.zeros(48, dtype=torch.int32, device="cuda")
     st = torch.empty(2 * N, dtype=torch.float64, device="cuda")
     scale = (A.double().abs() @ W.double().abs().t()) + b.double().abs()          # per-element sum |a||w|
-    for variant in (0, 2, 3, 4, 8, 9, 10):  # 11-15 are timing experiments with wrong results
+    for variant in (0, 2, 3, 4, 8, 9, 10, 11):  # 12-17 are timing experiments with wrong results
         Y = torch.full((M, N), float("nan"), device="cuda")
         run(M, K, N, variant, A, W, b, Y, work, scr, st)
         torch.cuda.synchronize()
