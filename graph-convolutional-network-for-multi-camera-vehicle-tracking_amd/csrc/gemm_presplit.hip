@@ -600,11 +600,15 @@ __global__ __launch_bounds__(512, 1) void gemm_f16p_m16_kernel(SplitGemmParams p
       f16x8 a[2];
 #pragma unroll
       for (int q = 0; q < 2; ++q) a[q] = *reinterpret_cast<const f16x8*>(st + q * IMG + a_row + i * 16 * ROWB);
+      // the three products of a block go out back to back: the second and third take the accumulator the first just
+      // produced (1.072 ms against 1.101 ms for runs of four MFMAs on four different accumulators, same box: the chained
+      // form draws less power, and at the power cap that is time)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], b[j][0], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[j][1], acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[j][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[j][1], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
       }
     }
   };
