@@ -518,6 +518,48 @@ def add_measured_peak(res, probe):
         res["roofline"]["frac_of_measured_peak"] = res["roofline"]["achieved"] / peak
 
 
+def self_launch_command(args, port=None):
+    """`python bench.py --gpus N` WITHOUT a launcher (no RANK / WORLD_SIZE in the environment): the command that starts
+    the N ranks, exactly as the driver would -- one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1."""
+    import socket
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--workload", args.workload]
+    if args.no_stress:
+        cmd.append("--no-stress")
+    if args.no_cpu:
+        cmd.append("--no-cpu")
+    return cmd
+
+
+def launch_or_refuse(args):
+    """Called before anything touches a GPU.  Returns None when this process should run the bench itself, else the exit
+    code of the ranks it started (or 2 after printing why it cannot).  A `--gpus N` process never sits in a rendezvous
+    waiting for ranks nobody started."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None or "RANK" in os.environ:
+        world = int(env_world or "1")
+        if world != args.gpus and not (args.gpus == 1 and world >= 1):
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+            return 2
+        return None                                         # a rank of a launcher's job (torchrun): run
+    if args.gpus <= 1:
+        return None
+    import subprocess
+    have = torch.cuda.device_count()                        # (counting devices does not initialise the GPU)
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} asked for, {have} GPU(s) visible -- not starting a job that cannot "
+              "rendezvous", file=sys.stderr)
+        return 2
+    cmd = self_launch_command(args)
+    print("bench.py: no launcher environment (RANK / WORLD_SIZE); starting the ranks: " + " ".join(cmd), file=sys.stderr)
+    return subprocess.run(cmd).returncode                   # children inherit stdout: rank 0's JSON line is ours
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -528,6 +570,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
+    rc = launch_or_refuse(args)
+    if rc is not None:
+        sys.exit(rc)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or os.environ.get("MTMC_BENCH_FORCE_DIST"):
         from bench_dist import main_distributed   # multi-GPU leg lives beside this file

@@ -116,35 +116,63 @@ def main_distributed(args):
         dist.all_reduce(t2, op=dist.ReduceOp.MAX)
         sec_sharded_h = float(t2.item())
 
-    # per-phase split on this rank (kernels vs collectives), a few extra iterations with events
+    # per-phase split (kernels vs collectives) with events, and what the HOST spends per phase (issuing the phase's
+    # launches through mtmc_mpn_run_phase / issuing the collectives behind it), on every rank, a few extra iterations
     eng = model._engine
-    split = {"kernels_ms": 0.0, "collectives_ms": 0.0}
     with torch.no_grad():
         prep_evs = []
+        host_ms = {}
+
+        def host_add(key, t0):
+            host_ms[key] = host_ms.get(key, 0.0) + (time.perf_counter() - t0) * 1e3
+
+        class TimedBackend:
+            """The engine's phase interface with a host clock around run_phase (everything else passes through)."""
+            def __init__(self, inner):
+                self._inner = inner
+
+            def __getattr__(self, name):
+                return getattr(self._inner, name)
+
+            def run_phase(self, prep, ph, arg):
+                t0 = time.perf_counter()
+                self._inner.run_phase(prep, ph, arg)
+                host_add(bench.PHASE_NAMES.get(ph, str(ph)), t0)
 
         class Timed(mdist.ShardedForward):
-            def _sum(self, tns):
+            def _timed(self, fn, *a_):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(); super()._sum(tns); b.record(); prep_evs.append((a, b))
+                t0 = time.perf_counter()
+                a.record(); fn(*a_); b.record()
+                host_add("collectives", t0)
+                prep_evs.append((a, b))
+
+            def _sum(self, tns):
+                self._timed(super()._sum, tns)
 
             def _max(self, tns):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(); super()._max(tns); b.record(); prep_evs.append((a, b))
+                self._timed(super()._max, tns)
 
             def _gather_rows(self, *a_):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(); super()._gather_rows(*a_); b.record(); prep_evs.append((a, b))
-        timed = Timed(eng, model.spec)
+                self._timed(super()._gather_rows, *a_)
+        timed = Timed(TimedBackend(eng), model.spec)
         reps = 3
         s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t_host = time.perf_counter()
         s_ev.record()
         for _ in range(reps):
             timed(x_loc, (lo, hi, n), ei_loc, ea_loc, e, rr, own)
         e_ev.record()
+        host_total = (time.perf_counter() - t_host) * 1e3 / reps      # host time to ISSUE one forward (no sync inside)
         torch.cuda.synchronize(device)
         coll = sum(a.elapsed_time(b) for a, b in prep_evs) / reps
         total = s_ev.elapsed_time(e_ev) / reps
         split = {"collectives_ms": coll, "kernels_and_gather_ms": total - coll, "step_ms_this_rank": total}
+        mine = {"rank": rank, "host_issue_ms_per_forward": round(host_total, 4), "gpu_step_ms": round(total, 4),
+                "gpu_collectives_ms": round(coll, 4),
+                "host_ms_by_phase": {k: round(v / reps, 4) for k, v in sorted(host_ms.items())}}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     # the headline graph (AIC19-S02, N=450) on the same ranks: what BASELINE.json's metric names, although a
     # 150k-edge forward is latency-bound and gains nothing from more GPUs (reported beside the scaling workload)
@@ -197,7 +225,7 @@ def main_distributed(args):
                                  "headline"),
                 "forward_algorithmic": {"bytes": b_fwd, "GBps": b_fwd / sec / 1e9,
                                         "frac_of_aggregate_hbm_peak": b_fwd / sec / 1e9 / (bench.HBM_PEAK_GBS * world)},
-                "rank0_split": split, "parity_vs_1gpu": parity,
+                "rank0_split": split, "per_rank_host": per_rank, "parity_vs_1gpu": parity,
                 "ms_per_step_with_sharded_node_state": None if sec_sharded_h is None else sec_sharded_h * 1e3}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())

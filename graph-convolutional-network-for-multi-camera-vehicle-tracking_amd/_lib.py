@@ -50,6 +50,16 @@ class WsLayout(C.Structure):
                 ("P_off", C.c_size_t)]
 
 
+class Plan(C.Structure):
+    """mtmc_mpn_plan: which kernels a call would run (host-only query)."""
+    _fields_ = [("enc_kernel", C.c_int32 * MAX_ENC_LAYERS), ("enc_split_k", C.c_int32 * MAX_ENC_LAYERS),
+                ("edges_per_thread", C.c_int32), ("lazy_edges", C.c_int32), ("pass_c", C.c_int32),
+                ("avg_degree", C.c_double)]
+
+
+GEMM_GENERIC, GEMM_INLOOP_64, GEMM_INLOOP_128, GEMM_PRESPLIT_256 = range(4)
+PASS_C_WALK, PASS_C_MFMA_SORTED, PASS_C_MFMA_ANY = range(3)
+
 # statistics blocks (include/mtmc_mpn.h): replicas x stride doubles each
 STAT_REPLICAS, ATTR_STRIDE, ENC2_STRIDE, Z1_STRIDE, M_STRIDE, Z2_STRIDE = 16, 16, 16, 16, 16, 64
 ROUND_BLOCK = STAT_REPLICAS * (Z1_STRIDE + M_STRIDE + Z2_STRIDE)
@@ -57,7 +67,7 @@ F_DETERMINISTIC, F_GLOBAL_DEG, F_FORK = 1, 4, 2
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmtmc_mpn.so")
 EXPORTS = ["mtmc_mpn_abi_version", "mtmc_mpn_last_error", "mtmc_mpn_workspace_bytes", "mtmc_mpn_workspace_layout",
-           "mtmc_mpn_forward", "mtmc_mpn_run_phase", "mtmc_scatter_add", "mtmc_scatter_add_i64", "mtmc_scatter_mean", "mtmc_scatter_max",
+           "mtmc_mpn_forward", "mtmc_mpn_run_phase", "mtmc_mpn_plan_call", "mtmc_scatter_add", "mtmc_scatter_add_i64", "mtmc_scatter_mean", "mtmc_scatter_max",
            "mtmc_mlp_layer_forward", "mtmc_mpn_train_workspace_bytes", "mtmc_mpn_backward", "mtmc_graph_workspace_bytes",
            "mtmc_build_graph", "mtmc_postprocess_workspace_bytes", "mtmc_postprocess",
            "mtmc_cross_entropy_forward", "mtmc_cross_entropy_backward",
@@ -129,6 +139,8 @@ def load() -> C.CDLL:
     lib.mtmc_postprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
                                      C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_void_p]
+    lib.mtmc_mpn_plan_call.restype = C.c_int32
+    lib.mtmc_mpn_plan_call.argtypes = [C.POINTER(Model), C.POINTER(Call), C.POINTER(Plan)]
     lib.mtmc_mpn_run_phase.restype = C.c_int32
     lib.mtmc_mpn_run_phase.argtypes = [C.POINTER(Model), C.POINTER(Call), C.c_int32, C.c_int32]
     for name in ("mtmc_scatter_add", "mtmc_scatter_add_i64"):
@@ -143,7 +155,7 @@ def load() -> C.CDLL:
     lib.mtmc_mlp_layer_forward.restype = C.c_int32
     lib.mtmc_mlp_layer_forward.argtypes = [C.POINTER(Layer), C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                            C.c_void_p]
-    if lib.mtmc_mpn_abi_version() != 3:
+    if lib.mtmc_mpn_abi_version() != 4:
         raise RuntimeError("mtmc_mpn: ABI version mismatch between _lib.py and libmtmc_mpn.so")
     _lib = lib
     return lib

@@ -65,6 +65,35 @@ int32_t mtmc_mpn_run_phase(const mtmc_mpn_model* model, const mtmc_mpn_call* cal
   return run_phase(x, phase, arg);
 }
 
+int32_t mtmc_mpn_plan_call(const mtmc_mpn_model* model, const mtmc_mpn_call* call, mtmc_mpn_plan* out) {
+  if (int rc = check_model(model)) return rc;
+  if (!call || !out) return fail(MTMC_E_ARG, "mtmc_mpn_plan_call: NULL call or result");
+  const mtmc_mpn_call* c = call;
+  if (c->n_nodes < 0 || c->n_edges < 0 || c->n_edges > c->n_edges_total || c->node_lo < 0 || c->node_hi < c->node_lo ||
+      c->node_hi > c->n_nodes || c->row_lo < 0 || c->row_hi < c->row_lo || c->row_hi > c->n_nodes)
+    return fail(MTMC_E_ARG, "mtmc_mpn_plan_call: sizes / ranges out of order");
+  *out = mtmc_mpn_plan();
+  const int64_t rows = c->node_hi - c->node_lo;
+  const bool pre0 = !c->training && mtmc::presplit_layer0(c->n_nodes, model->enc_node[0].in_dim, model->enc_node[0].out_dim) &&
+                    mtmc::presplit_layer0(rows, model->enc_node[0].in_dim, model->enc_node[0].out_dim);
+  for (int l = 0; l < model->n_enc_layers; ++l) {
+    const mtmc_layer& L = model->enc_node[l];
+    int sk_full = 1, sk_here = 1;
+    mtmc::gemm_plan(c->n_nodes, L.in_dim, L.out_dim, &sk_full);
+    const int cfg = rows > 0 ? mtmc::gemm_plan(rows, L.in_dim, L.out_dim, &sk_here) : 0;
+    const bool slab = sk_here > 1 && (size_t)sk_here * rows <= (size_t)(sk_full > 1 ? sk_full : 0) * c->n_nodes;   // run_phase
+    out->enc_kernel[l] = (l == 0 && pre0) ? MTMC_GEMM_PRESPLIT_256 : cfg == 2 ? MTMC_GEMM_INLOOP_128 : cfg == 1 ? MTMC_GEMM_INLOOP_64
+                                                                                                           : MTMC_GEMM_GENERIC;
+    out->enc_split_k[l] = ((l == 0 && pre0) || !slab) ? 1 : sk_here;
+  }
+  out->edges_per_thread = mtmc::plan_edges_per_thread(c->n_edges);
+  out->lazy_edges = lazy_edges(c) ? 1 : 0;
+  out->avg_degree = avg_degree(c);
+  const bool drop_n = c->training && model->dropout_upd_node > 0.f;
+  out->pass_c = mtmc::plan_pass_c(model->agg, (c->flags & MTMC_F_DETERMINISTIC) != 0, drop_n, c->n_edges, out->avg_degree);
+  return MTMC_OK;
+}
+
 int32_t mtmc_mpn_forward(const mtmc_mpn_model* model, const mtmc_mpn_call* call) {
   Ctx x;
   if (int rc = make_ctx(model, call, &x)) return rc;

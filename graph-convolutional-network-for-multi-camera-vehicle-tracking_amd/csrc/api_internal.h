@@ -252,6 +252,17 @@ inline float* round_Q(const Ctx& x, int r) { return x.at<float>(x.lo.training ? 
 inline float* round_z(const Ctx& x, int r) { return x.at<float>(x.lo.training ? x.lo.z_tr[r] : x.lo.e_buf[r & 1]); }
 inline float* round_e(const Ctx& x, int r) { return x.at<float>(x.lo.training ? x.lo.e_tr[r] : x.lo.e_buf[r & 1]); }
 
+// edges per source row of this call's edges -- what the pass-C dispatch needs.  Row-complete shard: local edges over the
+// rows the call owns; anything else (one GPU, or an edge-range shard that shares rows with its neighbours): the whole
+// graph's E / N.  (Round 2 divided the LOCAL edge count by the GLOBAL node count: 8 ranks of config 5 saw 12 instead of
+// 100 and left the matrix-core kernel.)
+inline double avg_degree(const mtmc_mpn_call* c) {
+  if (c->row_hi > 0) return c->row_hi > c->row_lo ? (double)c->n_edges / (double)(c->row_hi - c->row_lo) : 0.0;
+  return c->n_nodes > 0 ? (double)c->n_edges_total / (double)c->n_nodes : 0.0;
+}
+// eval mode, many local edges: e' is never stored (passes B/C and the next round's pass A recompute it from z1)
+inline bool lazy_edges(const mtmc_mpn_call* c) { return !c->training && c->n_edges > 2048 * 256; }
+
 inline mtmc::RoundParams round_params(const Ctx& x, int r) {
   const mtmc_mpn_model* m = x.m;
   const int hn = (m->reattach_nodes ? 2 : 1) * MTMC_NODE_DIM;
@@ -269,7 +280,7 @@ inline mtmc::RoundParams round_params(const Ctx& x, int r) {
   p.cls_w = m->cls.weight; p.cls_b = m->cls.bias; p.n_classes = m->cls.out_dim;
   p.stats = x.at<double>(x.lo.pub.stat_round_off) + (size_t)r * mtmc::kRoundBlock;
   // (few-edge graphs are latency-bound: there the extra statistics gather in two prologues costs more than the bytes save)
-  p.lazy_e = (!x.lo.training && x.c->n_edges > 2048 * 256) ? 1 : 0;
+  p.lazy_e = lazy_edges(x.c) ? 1 : 0;
   p.prev_stats = r > 0 ? p.stats - mtmc::kRoundBlock : nullptr;
   p.seg = x.at<double>(x.lo.pub.seg_off);
   p.h_acc = agg_target(x, r);
@@ -282,6 +293,7 @@ inline mtmc::RoundParams round_params(const Ctx& x, int r) {
   p.det = (x.c->flags & MTMC_F_DETERMINISTIC) ? 1 : 0; p.flags = x.at<int>(x.lo.pub.flags_off);
   p.deg = x.at<int>(x.lo.pub.deg_off); p.row_start = x.at<int>(x.lo.row_start); p.carry = x.at<float>(x.lo.carry);
   p.n_nodes = x.c->n_nodes;
+  p.avg_degree = avg_degree(x.c);
   p.enc = enc_params(x);
   return p;
 }

@@ -244,7 +244,7 @@ extern "C" int32_t mtmc_mpn_backward_steps(const mtmc_mpn_model* model, const mt
 // and views it with the same rule (mtmc_mpn_grad_layout: offsets in floats, returns the total), instead of filling a
 // second 34-pointer struct per call.
 extern "C" int64_t mtmc_mpn_grad_layout(const mtmc_mpn_model* m, int64_t* offsets, int32_t max_offsets) {
-  if (!m) return 0;
+  if (!m || m->n_enc_layers < 1 || m->n_enc_layers > MTMC_MAX_ENC_LAYERS) return 0;   // (0 = no layout: bad model)
   int64_t total = 0;
   int n = 0;
   auto piece = [&](int64_t numel) {
@@ -268,6 +268,7 @@ extern "C" int32_t mtmc_mpn_backward_flat(const mtmc_mpn_model* model, const mtm
                                           const float* const* d_logits_steps, const float* d_h, float* flat,
                                           int64_t flat_floats, float* d_x, float* d_edge_attr) {
   if (!model || !flat) return fail(MTMC_E_ARG, "mtmc_mpn_backward_flat: NULL model or gradient buffer");
+  if (int rc = check_model(model)) return rc;          // before anything indexes enc_node[] / off[] by n_enc_layers
   int64_t off[4 * (MTMC_MAX_ENC_LAYERS + 4) + 2];
   const int64_t need = mtmc_mpn_grad_layout(model, off, (int32_t)(sizeof(off) / sizeof(off[0])));
   if (flat_floats < need) return fail(MTMC_E_ARG, "mtmc_mpn_backward_flat: gradient buffer too small");

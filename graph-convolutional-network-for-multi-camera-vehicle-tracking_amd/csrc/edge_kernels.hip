@@ -11,7 +11,6 @@
 //   pass_b_kernel      e' = relu(bn(z1)) stored; moments of e'; per-node segment sums of e'
 //   pass_c_kernel      m = relu(bn(Wn.[h[row]|e'] + bn)); h' = agg_row(m); logits  (NodeModel, mpn.py:97-99)
 //   classify_e0_kernel logits of the encoded edges when L == 0                      (mpn.py:295-297)
-#include <stdlib.h>
 #include "kernels.h"
 
 namespace mtmc {
@@ -126,37 +125,70 @@ __global__ __launch_bounds__(256) void enc2_kernel(EdgeEncParams enc, const floa
 // ------------------------------------------------------------------------------------------------
 // z1 of one edge: Pr[row] + Pc[col] + We_e . e_in + be
 // ------------------------------------------------------------------------------------------------
-struct EdgeUpdWeights { float w[4][8]; float b[4]; };
+// The small constants every edge needs in pass A -- the two edge-encoder layers with their BatchNorm affines (first round /
+// reattached edges: e0 is recomputed from the 8-byte attributes, never stored) and the edge-update weights.  Up to 84
+// floats: as uniform (scalar) operands they did not fit the SGPR file (105-160 spills, each a v_readlane in the loop; the
+// first round's launch took 220 us at config 4 against 133 us for the later rounds, which move MORE bytes).  They are
+// staged once per workgroup in LDS and read back by every lane into VECTOR registers: a load from LDS lands in a VGPR
+// and stays there.  Same arithmetic, same order as edge_enc_hidden / edge_enc_out (common.h).
+struct EdgeConsts {
+  float w1[4][2], b1[4], s1[4], t1[4];     // hidden layer (second column 0 when edge_in_dim == 1)
+  float w2[4][4], b2[4], s2[4], t2[4];     // output layer
+  float uw[4][8], ub[4];                   // edge update: the e columns of We (first 4: e0 when reattached, else e), bias
+};
+constexpr int kEdgeConstsN = sizeof(EdgeConsts) / sizeof(float);
 
-__device__ __forceinline__ void load_edge_upd_weights(const RoundParams& p, EdgeUpdWeights& w) {
-  const int nin = p.reattach_edges ? 8 : 4;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    w.b[k] = p.ue_b[k];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) w.w[k][j] = j < nin ? p.ue_w[k * p.ue_ld + p.ue_eoff + j] : 0.f;   // (dead columns fold away per MODE)
+// whole block; ends with a barrier.  MODE as in pass_a_kernel.
+template <int MODE>
+__device__ __forceinline__ void stage_edge_consts(const RoundParams& p, EdgeConsts* cs) {
+  float* dst = reinterpret_cast<float*>(cs);
+  for (int i = threadIdx.x; i < kEdgeConstsN; i += blockDim.x) {
+    float v = 0.f;
+    if (i < 8) { const int k = i >> 1, j = i & 1; v = (MODE != 0 && j < p.enc.fe) ? p.enc.w1[k * p.enc.fe + j] : 0.f; }
+    else if (i < 12) v = MODE != 0 ? p.enc.b1[i - 8] : 0.f;
+    else if (i < 20) v = MODE != 0 ? p.enc.aff[i - 12] : 0.f;                    // s1[4] | t1[4] of EdgeEncAffine
+    else if (i < 36) v = MODE != 0 ? p.enc.w2[i - 20] : 0.f;
+    else if (i < 40) v = MODE != 0 ? p.enc.b2[i - 36] : 0.f;
+    else if (i < 48) v = MODE != 0 ? p.enc.aff[8 + i - 40] : 0.f;                // s2[4] | t2[4]
+    else if (i < 80) {
+      const int k = (i - 48) >> 3, j = (i - 48) & 7;
+      v = j < ((MODE & 2) ? 8 : 4) ? p.ue_w[k * p.ue_ld + p.ue_eoff + j] : 0.f;
+    } else v = p.ue_b[i - 80];
+    dst[i] = v;
   }
+  __syncthreads();
 }
 
 struct PrevAffine { float s[4], t[4]; };   // BatchNorm affine of the previous round's z1 (lazy e')
 
-// MODE 0: a later round without reattached edges (no attribute loads, no edge-encoder arithmetic, 4 x 4 weights: the
-// general body's scalar operands do not fit the SGPR file -- 171 spills); bit 0: first round, bit 1: reattach_initial_edges
+// z1 of one edge: Pr[row] + Pc[col] + We_e . e_in + be.
+// MODE 0: a later round without reattached edges (no attribute loads, no edge-encoder arithmetic, 4 x 4 weights);
+// bit 0: first round, bit 1: reattach_initial_edges
 template <int MODE>
-__device__ __forceinline__ void edge_z1(const RoundParams& p, const EdgeEncAffine& af, const EdgeUpdWeights& w,
-                                        const PrevAffine& pa, int64_t e, int& r, float (&z)[4]) {
+__device__ __forceinline__ void edge_z1(const RoundParams& p, const EdgeConsts& c, const PrevAffine& pa, int64_t e, int& r,
+                                        float (&z)[4]) {
   constexpr bool first_round = (MODE & 1) != 0, reattach = (MODE & 2) != 0;
   r = p.row32[e];
-  const int c = p.col32[e];
+  const int col = p.col32[e];
   // P = [Pr: N x 4 | Pc: N x 4]: the randomly gathered half is a compact 16 B/node table (four nodes per 64-byte sector)
   const float4 pr = *reinterpret_cast<const float4*>(p.P + (int64_t)r * 4);
-  const float4 pc = *reinterpret_cast<const float4*>(p.P + ((int64_t)p.n_nodes + c) * 4);
+  const float4 pc = *reinterpret_cast<const float4*>(p.P + ((int64_t)p.n_nodes + col) * 4);
   float e0[4] = {0, 0, 0, 0}, ep[4];
   if (first_round || reattach) {
     float a0, a1, u[4];
     load_attr(p.attr, p.enc.fe, e, a0, a1);
-    edge_enc_hidden(p.enc, af, e, a0, a1, u);
-    edge_enc_out(p.enc, af, e, u, e0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                       // edge_enc_hidden
+      const float zz = fmaf(c.w1[k][1], a1, c.b1[k] + c.w1[k][0] * a0);
+      u[k] = drop_apply(p.enc.drop, kDropEncEdge1, (unsigned long long)e * 4 + k, fmaxf(fmaf(zz, c.s1[k], c.t1[k]), 0.f));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                       // edge_enc_out
+      float zz = c.b2[k];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) zz = fmaf(c.w2[k][j], u[j], zz);
+      e0[k] = drop_apply(p.enc.drop, kDropEncEdge2, (unsigned long long)e * 4 + k, fmaxf(fmaf(zz, c.s2[k], c.t2[k]), 0.f));
+    }
   }
   if (first_round) {
 #pragma unroll
@@ -172,15 +204,15 @@ __device__ __forceinline__ void edge_z1(const RoundParams& p, const EdgeEncAffin
   const float prv[4] = {pr.x, pr.y, pr.z, pr.w}, pcv[4] = {pc.x, pc.y, pc.z, pc.w};
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    float acc = prv[k] + pcv[k] + w.b[k];
+    float acc = prv[k] + pcv[k] + c.ub[k];
     if (reattach) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = fmaf(w.w[k][j], e0[j], acc);
+      for (int j = 0; j < 4; ++j) acc = fmaf(c.uw[k][j], e0[j], acc);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = fmaf(w.w[k][4 + j], ep[j], acc);
+      for (int j = 0; j < 4; ++j) acc = fmaf(c.uw[k][4 + j], ep[j], acc);
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = fmaf(w.w[k][j], ep[j], acc);
+      for (int j = 0; j < 4; ++j) acc = fmaf(c.uw[k][j], ep[j], acc);
     }
     z[k] = acc;
   }
@@ -191,23 +223,27 @@ __device__ __forceinline__ void edge_z1(const RoundParams& p, const EdgeEncAffin
 
 template <int kEPT, int MODE>
 __global__ __launch_bounds__(256) void pass_a_kernel(RoundParams p) {
-  __shared__ EdgeEncAffine af;
+  __shared__ EdgeConsts cs_s;
   __shared__ double red[8 * 4];
   __shared__ PrevAffine pa_s;
-  if (MODE != 0) edge_enc_affine_load(p.enc, &af);
   if (p.lazy_e && !(MODE & 1)) {
     stat_gather(p.prev_stats + kRoundZ1Off, 8, kZ1Stride, red);
     __syncthreads();
     if (threadIdx.x < 4)
       bn_affine(red[threadIdx.x], red[4 + threadIdx.x], p.e_total, p.ue_g[threadIdx.x], p.ue_bt[threadIdx.x],
                 pa_s.s[threadIdx.x], pa_s.t[threadIdx.x]);
-    __syncthreads();
   }
+  stage_edge_consts<MODE>(p, &cs_s);               // (barrier inside: pa_s is visible too)
   PrevAffine pa;
 #pragma unroll
   for (int j = 0; j < 4; ++j) { pa.s[j] = pa_s.s[j]; pa.t[j] = pa_s.t[j]; }
-  EdgeUpdWeights w;
-  load_edge_upd_weights(p, w);
+  EdgeConsts c;                                    // per-lane copy: VGPRs (only the fields MODE uses survive)
+  {
+    const float* src = reinterpret_cast<const float*>(&cs_s);
+    float* dst = reinterpret_cast<float*>(&c);
+#pragma unroll
+    for (int i = 0; i < kEdgeConstsN; ++i) dst[i] = src[i];
+  }
   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * kEPT;
   for (int64_t base = (int64_t)blockIdx.x * blockDim.x * kEPT + threadIdx.x; base < p.n_edges; base += stride) {
@@ -217,7 +253,7 @@ __global__ __launch_bounds__(256) void pass_a_kernel(RoundParams p) {
       const int64_t e = base + i * 256;
       int r;
       if (e < p.n_edges) {
-        edge_z1<MODE>(p, af, w, pa, e, r, z[i]);
+        edge_z1<MODE>(p, c, pa, e, r, z[i]);
         // the random 16-byte P[col] gather is what bounds this pass (one cache line per lane): do it once and
         // hand z1 to pass B through memory instead of gathering again there
         reinterpret_cast<float4*>(p.e_buf)[e] = make_float4(z[i][0], z[i][1], z[i][2], z[i][3]);
@@ -838,23 +874,22 @@ void launch_pass_b(const RoundParams& p, hipStream_t s) {
 // on the device).  mfma_c = 2 (few-edge lists, where a second launch would cost as much as the pass): the matrix-core
 // kernel alone, whatever the order -- it is correct for any order, groups that touch many rows just take one masked pass
 // per row.  MTMC_PASS_C_WALK=1 keeps the walk everywhere (A/B).
-static int use_mfma_c(const RoundParams& p) {
-  static const bool off = getenv("MTMC_PASS_C_WALK") != nullptr;
-  static const int64_t small_min = getenv("MTMC_PASS_C_SMALL_MIN") ? atoll(getenv("MTMC_PASS_C_SMALL_MIN")) : 32768;
-  if (off || p.agg == 2 || p.det || p.drop_n.on || p.n_nodes <= 0 || p.n_edges / p.n_nodes < 24) return 0;
-  if (p.n_edges > kSmallEdges) return 1;
-  return p.n_edges >= small_min ? 2 : 0;
+int plan_pass_c(int agg, bool deterministic, bool dropout, int64_t n_edges, double avg_degree) {
+  const Knobs& kn = knobs();
+  if (kn.pass_c_walk || agg == 2 || deterministic || dropout || avg_degree < 24.0) return 0;
+  if (n_edges > kSmallEdges) return 1;
+  return n_edges >= kn.pass_c_small_min ? 2 : 0;
 }
+int plan_edges_per_thread(int64_t n_edges) { return pick_ept(n_edges); }
 
 void launch_pass_c(const RoundParams& p0, hipStream_t s) {
   RoundParams p = p0;
-  p.mfma_c = use_mfma_c(p);
+  p.mfma_c = plan_pass_c(p.agg, p.det != 0, p.drop_n.on != 0, p.n_edges, p.avg_degree);
   if (p.mfma_c) {
     // many edges: a resident grid (the block prologue -- 74 replicated statistics, one BatchNorm affine per channel -- is
     // paid once per block, so blocks live long) whose waves take short spans round-robin (~6 spans per wave at config 4);
     // few edges: one 64-edge chunk per wave, as many waves as there are chunks
-    static const int span_env = getenv("MTMC_PASS_C_SPAN") ? atoi(getenv("MTMC_PASS_C_SPAN")) : 0;
-    static const int max_blocks = getenv("MTMC_PASS_C_BLOCKS") ? atoi(getenv("MTMC_PASS_C_BLOCKS")) : 256 * 6;
+    const int span_env = knobs().pass_c_span, max_blocks = knobs().pass_c_blocks;
     const int span_c = span_env > 0 ? span_env : (p.mfma_c == 2 ? 1 : 8);
     const int64_t spans = ((p.n_edges + 63) / 64 + span_c - 1) / span_c, blocks = (spans + 3) / 4;
     hipLaunchKernelGGL(pass_c_mfma_kernel, dim3((int)(blocks > max_blocks ? max_blocks : blocks)), dim3(256), 0, s, p, span_c);

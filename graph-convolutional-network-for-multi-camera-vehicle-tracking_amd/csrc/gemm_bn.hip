@@ -829,8 +829,8 @@ int gemm_plan(int64_t M, int K, int Nout, int* split_k, bool long_k_ok) {
 // which: 1 = the GEMM only, 2 = the split-K combine only (no-op for un-split layers), 3 = both
 int launch_gemm_bn(const GemmParams& p, hipStream_t s, int which) {
   if (p.M < 1 || p.Nout < 1 || p.K < 1) return MTMC_E_ARG;
-  static const bool fp32_only_env = getenv("MTMC_GEMM_FP32") != nullptr, no_f16_env = getenv("MTMC_GEMM_NO_F16") != nullptr;
-  const bool f16_ok = p.amax_a && p.amax_w && !fp32_only_env && !no_f16_env;
+  const bool fp32_only = knobs().gemm_fp32, no_f16 = knobs().gemm_no_f16;
+  const bool f16_ok = p.amax_a && p.amax_w && !fp32_only && !no_f16;
   const bool long_k_ok = f16_ok;          // the fp16 kernel keeps at most kAffChunk affine columns in LDS at a time
   if (p.K % 32 != 0 || (p.K > 6144 && !long_k_ok) || (p.lda % 4) != 0 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) {
     if (p.stats_in != nullptr || p.Nout > 2048) return MTMC_E_ARG;
@@ -845,9 +845,7 @@ int launch_gemm_bn(const GemmParams& p, hipStream_t s, int which) {
   const int cfg = gemm_plan(p.M, p.K, p.Nout, &sk, long_k_ok);
   q.split_k = (p.slab != nullptr) ? sk : 1;
   if (which & 1) {
-    static const bool fp32_only = getenv("MTMC_GEMM_FP32") != nullptr;
-    static const bool no_f16 = getenv("MTMC_GEMM_NO_F16") != nullptr;
-    const bool f16 = p.amax_a && p.amax_w && !fp32_only && !no_f16;
+    const bool f16 = f16_ok;
     int rc = MTMC_OK;
     if (cfg == 2 && f16 && p.K % 64 == 0) rc = launch_f16x3<2, 2, 64>(q, s);
     else if (cfg == 2 && f16) rc = launch_f16x3<2, 2, 32>(q, s);

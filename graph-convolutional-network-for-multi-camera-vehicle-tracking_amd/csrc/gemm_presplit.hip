@@ -901,7 +901,7 @@ static int launch_variant(const SplitGemmParams& p, hipStream_t s) {
 }
 
 bool presplit_layer0(int64_t rows, int K, int Nout) {
-  static const bool off = getenv("MTMC_GEMM_NO_PRESPLIT") != nullptr || getenv("MTMC_GEMM_FP32") != nullptr || getenv("MTMC_GEMM_NO_F16") != nullptr;
+  const bool off = knobs().gemm_no_presplit || knobs().gemm_fp32 || knobs().gemm_no_f16;
   int sk;
   return !off && K % 64 == 0 && K <= 2048 && rows >= 4096 && gemm_plan(rows, K, Nout, &sk) == 2;
 }

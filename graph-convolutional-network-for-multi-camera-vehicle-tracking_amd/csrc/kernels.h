@@ -5,6 +5,19 @@
 
 namespace mtmc {
 
+// Optional A/B switches from the environment, read ONCE per process (knobs.hip) -- the launch paths
+// only look at this struct.
+struct Knobs {
+  bool pass_c_walk;          // MTMC_PASS_C_WALK: pass C on the half-wave walk everywhere
+  int64_t pass_c_small_min;  // MTMC_PASS_C_SMALL_MIN: fewest edges for the matrix-core pass C on few-edge lists
+  int pass_c_span;           // MTMC_PASS_C_SPAN: 64-edge chunks per wave span (0 = default)
+  int pass_c_blocks;         // MTMC_PASS_C_BLOCKS: resident grid of the matrix-core pass C
+  bool gemm_fp32;            // MTMC_GEMM_FP32: exact-fp32 MFMA encoder everywhere
+  bool gemm_no_f16;          // MTMC_GEMM_NO_F16: bf16x6 (large) / exact fp32 (few rows) instead of the fp16 split kernels
+  bool gemm_no_presplit;     // MTMC_GEMM_NO_PRESPLIT: layer 0 of many-row graphs on the in-loop kernel
+};
+const Knobs& knobs();
+
 // |.|max of a [rows][cols] fp32 matrix (row stride ld), accumulated with atomicMax on the bit pattern: scales of the
 // fp16 two-piece node-encoder GEMM.  Done by extra workgroups of prep_kernel, i.e. without a launch of its own.
 constexpr int kAmaxRep = 16;   // replicas of every |.|max word: same-address atomics serialise in L2
@@ -43,6 +56,9 @@ struct RoundParams {
   int lazy_e; const double* prev_stats;
   int mfma_c;                // set by launch_pass_c: the matrix-core pass C takes row-sorted lists
   int det; const int* flags; const int* deg; const int* row_start; float* carry; int64_t n_nodes;   // deterministic sums
+  // edges per SOURCE ROW of this call's edges: local edges / owned rows for a row-complete shard, E_total / N otherwise
+  // (a shard's local edge count over the GLOBAL node count would send 8 ranks of config 5 to the slow walk)
+  double avg_degree;
   EdgeEncParams enc;
 };
 
@@ -114,6 +130,11 @@ void launch_enc2(const EdgeEncParams& enc, const float* attr, int64_t n_edges, d
 void launch_pass_a(const RoundParams& p, hipStream_t s);
 void launch_pass_b(const RoundParams& p, hipStream_t s);
 void launch_pass_c(const RoundParams& p, hipStream_t s);
+// Which pass-C kernel a call takes (host-only decision, also behind mtmc_mpn_plan): 0 = the half-wave walk; 1 = the
+// matrix-core kernel with the walk launched behind it for unsorted rows (many-edge lists); 2 = the matrix-core kernel
+// alone (few-edge lists).  avg_degree: edges per source row of THIS call's edges (RoundParams::avg_degree).
+int plan_pass_c(int agg, bool deterministic, bool dropout, int64_t n_edges, double avg_degree);
+int plan_edges_per_thread(int64_t n_edges);      // passes A / B: 1 on few-edge lists, 4 otherwise
 void launch_classify_e0(const EdgeEncParams& enc, const float* attr, int64_t n_edges, double e_total,
                         const float* cls_w, const float* cls_b, int n_classes, float* logits, hipStream_t s);
 

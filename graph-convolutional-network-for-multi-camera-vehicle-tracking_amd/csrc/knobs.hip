@@ -1,0 +1,29 @@
+// The optional environment switches of DESIGN.md 7b, read once per process.  Kept in a translation unit of its own so
+// that both libmtmc_mpn.so and the kernel laboratory (lab/, libmtmc_lab.so) link the same reader.
+#include <stdlib.h>
+
+#include "kernels.h"
+
+namespace mtmc {
+
+static Knobs read_knobs() {
+  Knobs k;
+  auto on = [](const char* name) { return getenv(name) != nullptr; };
+  auto num = [](const char* name, long long dflt) { const char* v = getenv(name); return v ? atoll(v) : dflt; };
+  k.pass_c_walk = on("MTMC_PASS_C_WALK");
+  k.pass_c_small_min = num("MTMC_PASS_C_SMALL_MIN", 32768);
+  k.pass_c_span = (int)num("MTMC_PASS_C_SPAN", 0);
+  k.pass_c_blocks = (int)num("MTMC_PASS_C_BLOCKS", 256 * 6);
+  if (k.pass_c_blocks < 1) k.pass_c_blocks = 256 * 6;
+  k.gemm_fp32 = on("MTMC_GEMM_FP32");
+  k.gemm_no_f16 = on("MTMC_GEMM_NO_F16");
+  k.gemm_no_presplit = on("MTMC_GEMM_NO_PRESPLIT");
+  return k;
+}
+
+const Knobs& knobs() {
+  static const Knobs k = read_knobs();
+  return k;
+}
+
+}  // namespace mtmc

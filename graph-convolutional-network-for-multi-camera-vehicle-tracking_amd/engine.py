@@ -69,27 +69,21 @@ class ForwardEngine:
             self.module, self.spec = module_or_spec, module_or_spec.spec
         self.lib = _lib.load()
         self._ws = {}
-        self._layers = None             # param_layers(): the module tree is fixed after construction
         self._slots = layer_slots(self.spec)
-        self._default_params = None
         self._ms_key, self._ms = None, None
         self.flags = 0                  # MTMC_F_* for the calls this engine prepares (torch op argument)
 
     # -- parameters -> mtmc_mpn_model ------------------------------------------------------------
     def param_layers(self):
         """(struct slot, Linear, BatchNorm or None, LayerSpec) for every layer of the bound module."""
-        if self._layers is None:
-            if self.module is None:
-                raise RuntimeError("mtmc_mpn: this engine was built from a spec; pass the parameter list explicitly")
-            self._layers = module_layers(self.module)
-        return self._layers
+        if self.module is None:
+            raise RuntimeError("mtmc_mpn: this engine was built from a spec; pass the parameter list explicitly")
+        return module_layers(self.module)          # re-read per call: sub-modules / Parameters may have been replaced
 
     def params(self) -> List[torch.Tensor]:
-        if self._default_params is None:
-            self._default_params = ordered_params(self.module) if self.module is not None else None
-        if self._default_params is None:
+        if self.module is None:
             raise RuntimeError("mtmc_mpn: no parameters given")
-        return self._default_params
+        return ordered_params(self.module)         # never cached: see MOTMPNet.forward
 
     def model_struct(self, dev, params=None) -> _lib.Model:
         params = self.params() if params is None else params
@@ -125,6 +119,22 @@ class ForwardEngine:
         out.reattach_nodes, out.reattach_edges = int(s.reattach_nodes), int(s.reattach_edges)
         self._ms_key, self._ms = key, out
         return _lib.Model.from_buffer_copy(out)
+
+    def shape_model(self) -> _lib.Model:
+        """The configuration's dimensions and flags with PLACEHOLDER parameter pointers (non-NULL, never dereferenced):
+        for the host-only size queries (workspace bytes, gradient layout) that shape inference needs without tensors."""
+        s = self.spec
+        out = _lib.Model()
+        for slot, idx, layer in self._slots:
+            dst = getattr(out, slot) if idx is None else getattr(out, slot)[idx]
+            dst.weight = dst.bias = 256
+            dst.gamma = dst.beta = 256 if layer.bn_slot is not None else None
+            dst.in_dim, dst.out_dim = layer.in_dim, layer.out_dim
+        out.n_enc_layers = len(s.enc_node)
+        out.agg = _lib.AGG[s.agg]
+        out.num_enc_steps, out.num_class_steps = s.num_enc_steps, s.num_class_steps
+        out.reattach_nodes, out.reattach_edges = int(s.reattach_nodes), int(s.reattach_edges)
+        return out
 
     def workspace(self, model, n, e, dev, stream_ptr) -> torch.Tensor:
         need = self.lib.mtmc_mpn_workspace_bytes(C.byref(model), n, e)
@@ -216,6 +226,27 @@ class ForwardEngine:
         keep = (x, edge_index, edge_attr)        # the structs hold raw pointers: keep the tensors alive
         return types.SimpleNamespace(model=model, call=call, ws=ws, logits=logits, h=h, n_out=n_out, n=n, e=e,
                                      dev=dev, keep=keep)
+
+    def plan(self, n_nodes, n_edges, n_edges_total=None, node_range=None, row_range=None, training=False, flags=0,
+             params=None, device=None) -> types.SimpleNamespace:
+        """Which kernels a call of these sizes would run (mtmc_mpn_plan_call: host-only, nothing is launched and no GPU
+        is needed) -- lets a multi-GPU host, or a test, check that a shard takes the kernels the whole graph would."""
+        params = self.params() if params is None else params
+        model = self.model_struct(params[0].device if device is None else device, params)
+        call = _lib.Call()
+        call.n_nodes, call.n_edges = int(n_nodes), int(n_edges)
+        call.n_edges_total = int(n_edges if n_edges_total is None else n_edges_total)
+        call.node_lo, call.node_hi = (0, int(n_nodes)) if node_range is None else (int(node_range[0]), int(node_range[1]))
+        if row_range is not None:
+            rlo, rhi = int(row_range[0]), int(row_range[1])
+            call.row_lo, call.row_hi = (rlo, rhi) if rhi > rlo else (max(rlo, 1), max(rlo, 1))
+        call.training, call.flags = int(bool(training)), int(flags)
+        out = _lib.Plan()
+        _lib.check(self.lib.mtmc_mpn_plan_call(C.byref(model), C.byref(call), C.byref(out)))
+        n_layers = len(self.spec.enc_node)
+        return types.SimpleNamespace(enc_kernel=list(out.enc_kernel)[:n_layers], enc_split_k=list(out.enc_split_k)[:n_layers],
+                                     edges_per_thread=out.edges_per_thread, lazy_edges=bool(out.lazy_edges),
+                                     pass_c=out.pass_c, avg_degree=out.avg_degree)
 
     def phase_list(self):
         """(phase, arg) pairs of one forward, in order (what mtmc_mpn_forward runs internally)."""

@@ -169,12 +169,14 @@ class MOTMPNet(nn.Module):
         if self._engine is None:
             self._engine = engine.ForwardEngine(self)
             self._config_key = torch_ops.config_key(self.model_params, self.arch)
-            self._params = engine.ordered_params(self)
         x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr      # (shapes / dtypes: engine.prepare)
         if not (isinstance(x, torch.Tensor) and x.is_cuda):
             raise RuntimeError("mtmc_mpn: data.x / edge_index / edge_attr must be on a ROCm GPU -- "
                                "this module has no CPU or PyTorch fallback path")
-        params = self._params
+        # read from the module tree on EVERY call (34 attribute reads): a Parameter object replaced after the first forward
+        # (load_state_dict(assign=True), to_empty, parametrizations, `layer.weight = nn.Parameter(...)`) must be the one
+        # that is used and that receives the gradient
+        params = engine.ordered_params(self)
         needs_grad = torch.is_grad_enabled() and (
             x.requires_grad or edge_attr.requires_grad or any(p.requires_grad for p in params))
         tape = bool(needs_grad or self.training)

@@ -56,12 +56,19 @@ _GRAD_LAYOUTS = {}
 def grad_layout(spec):
     """(offset, numel, shape) of every parameter gradient inside the flat buffer mp_backward returns (256-byte pieces;
     the rule of mtmc_mpn_grad_layout in csrc/api_train.hip)."""
-    hit = _GRAD_LAYOUTS.get(id(spec))
+    key = tuple((slot, idx, layer.in_dim, layer.out_dim, layer.bn_slot is not None)
+                for slot, idx, layer in _layer_slots(spec))      # by content: id(spec) can be reused after a collection
+    hit = _GRAD_LAYOUTS.get(key)
     if hit is not None:
         return hit
     res = _grad_layout(spec)
-    _GRAD_LAYOUTS[id(spec)] = res
+    _GRAD_LAYOUTS[key] = res
     return res
+
+
+def _layer_slots(spec):
+    from .engine import layer_slots
+    return layer_slots(spec)
 
 
 def _grad_layout(spec):
@@ -89,7 +96,7 @@ torch.library.define(
     "bool tape) -> (Tensor, Tensor, Tensor)")
 torch.library.define(
     "mtmc_mpn::mp_backward",
-    "(Tensor tape, Tensor x, Tensor edge_index, Tensor edge_attr, Tensor[] params, str config, bool training, int seed, "
+    "(Tensor(a!) tape, Tensor x, Tensor edge_index, Tensor edge_attr, Tensor[] params, str config, bool training, int seed, "
     "int flags, Tensor? d_logits, Tensor? d_h, bool need_x, bool need_attr) -> (Tensor, Tensor, Tensor)")
 torch.library.define("mtmc_mpn::encode_nodes", "(Tensor x, Tensor[] params, str config) -> Tensor")
 torch.library.define("mtmc_mpn::scatter_add", "(Tensor src, Tensor index, int dim, int? dim_size) -> Tensor")
@@ -123,10 +130,15 @@ def _mp_forward(x, edge_index, edge_attr, params, config, training, seed, flags,
 
 @torch.library.register_fake("mtmc_mpn::mp_forward")
 def _mp_forward_fake(x, edge_index, edge_attr, params, config, training, seed, flags, tape):
-    spec = engine_for(config).spec
+    eng = engine_for(config)
+    spec = eng.spec
     e = edge_index.shape[1]
+    tape_bytes = 0
+    if tape:                                   # the real op returns the training workspace: size it from the dimensions
+        model = eng.shape_model()
+        tape_bytes = int(eng.lib.mtmc_mpn_train_workspace_bytes(C.byref(model), int(x.shape[0]), int(e))) + 256
     return (x.new_empty((_n_out(spec), e, spec.cls_edge[0].out_dim)), x.new_empty((x.shape[0], spec.node_dim)),
-            x.new_empty((0,), dtype=torch.uint8))
+            x.new_empty((tape_bytes,), dtype=torch.uint8))
 
 
 @torch.library.impl("mtmc_mpn::mp_backward", "CUDA")
@@ -200,10 +212,22 @@ torch.library.register_autograd("mtmc_mpn::mp_forward", _autograd_backward, setu
 @torch.library.impl("mtmc_mpn::encode_nodes", "CUDA")
 def _encode_nodes(x, params, config):
     from . import ops
+    from .engine import _check_param
     eng = engine_for(config)
     layers = eng.spec.enc_node
     if x.dim() != 2 or x.shape[1] != layers[0].in_dim or len(params) != 4 * len(layers):
         raise RuntimeError("mtmc_mpn.encode_nodes: x must be [N, in_dim] and params the 4 tensors of every encoder layer")
+    if x.dtype != torch.float32:
+        raise RuntimeError("mtmc_mpn.encode_nodes: x must be float32")
+    # every pointer below goes to the kernels as is: device, dtype, contiguity and shape are checked HERE (a CPU, fp16,
+    # strided or short tensor would be a wild read on the GPU)
+    for i, layer in enumerate(layers):
+        w, b, g, beta = params[4 * i:4 * i + 4]
+        for t in (w, b, g, beta):
+            _check_param(t, x.device)
+        if tuple(w.shape) != (layer.out_dim, layer.in_dim) or any(tuple(t.shape) != (layer.out_dim,) for t in (b, g, beta)):
+            raise RuntimeError(f"mtmc_mpn.encode_nodes: parameter shapes of encoder layer {i} do not match the configuration "
+                               f"([{layer.out_dim}, {layer.in_dim}] weight, [{layer.out_dim}] bias / gamma / beta)")
     a = x
     for i, layer in enumerate(layers):
         w, b, g, beta = params[4 * i:4 * i + 4]
@@ -221,6 +245,11 @@ def _scatter_args(src, index, dim, dim_size):
         raise NotImplementedError("mtmc_mpn.scatter_*: only dim=0 (the reference's call form) is implemented")
     if index.dim() != 1 or index.shape[0] != src.shape[0]:
         raise RuntimeError("mtmc_mpn.scatter_*: index must be 1-D with one entry per row of src")
+    if not src.is_cuda or index.device != src.device:
+        raise RuntimeError(f"mtmc_mpn.scatter_*: src and index must be on the same ROCm device (got {src.device} and "
+                           f"{index.device}); there is no CPU path")
+    if index.dtype not in (torch.int64, torch.int32):
+        raise RuntimeError("mtmc_mpn.scatter_*: index must be an integer tensor")
     if dim_size is None:
         dim_size = int(index.max()) + 1 if index.numel() else 0
     return src.reshape(src.shape[0], -1).contiguous(), index.contiguous().long(), int(dim_size)

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MTMC_MPN_ABI_VERSION 3
+#define MTMC_MPN_ABI_VERSION 4
 
 #define MTMC_MAX_ENC_LAYERS 8   /* hidden layers of the node encoder MLP          */
 #define MTMC_NODE_DIM 32        /* H : width of the node state the kernels are built for */
@@ -193,6 +193,23 @@ int32_t mtmc_mpn_backward_flat(const mtmc_mpn_model* model, const mtmc_mpn_call*
                                const float* const* d_logits_steps, const float* d_h, float* flat, int64_t flat_floats,
                                float* d_x, float* d_edge_attr);
 int32_t mtmc_mpn_run_phase(const mtmc_mpn_model* model, const mtmc_mpn_call* call, int32_t phase, int32_t arg);
+
+/* Which kernels a call would run -- a host-only query (nothing is launched, no pointer of `call` is read: only its
+ * sizes, ranges, flags and `training`), so that a multi-GPU host or a test can check that a SHARD takes the kernels the
+ * whole graph would.  Encoder layers are planned for the node_hi - node_lo rows the call encodes. */
+enum { MTMC_GEMM_GENERIC = 0, MTMC_GEMM_INLOOP_64 = 1, MTMC_GEMM_INLOOP_128 = 2, MTMC_GEMM_PRESPLIT_256 = 3 };
+enum { MTMC_PASS_C_WALK = 0, MTMC_PASS_C_MFMA_SORTED = 1, MTMC_PASS_C_MFMA_ANY = 2 };
+typedef struct mtmc_mpn_plan {
+  int32_t enc_kernel[MTMC_MAX_ENC_LAYERS];   /* MTMC_GEMM_*: one-thread-per-output fallback / in-loop operand split on
+                                                64x64 or 128x128 tiles / pre-split fp16 planes + 256x256 tiles      */
+  int32_t enc_split_k[MTMC_MAX_ENC_LAYERS];  /* K slices (few-row layers; > 1 => MTMC_PH_NODE_COMBINE does work)    */
+  int32_t edges_per_thread;                  /* passes A / B                                                        */
+  int32_t lazy_edges;                        /* 1: e' is never stored, consumers recompute it from z1               */
+  int32_t pass_c;                            /* MTMC_PASS_C_*: half-wave walk / matrix-core kernel + the walk launched
+                                                behind it for unsorted rows / matrix-core kernel alone               */
+  double avg_degree;                         /* edges per source row the pass-C choice was made on                  */
+} mtmc_mpn_plan;
+int32_t mtmc_mpn_plan_call(const mtmc_mpn_model* model, const mtmc_mpn_call* call, mtmc_mpn_plan* out);
 
 /* out[dim_size, C] (fp32) <- scatter of src[E, C] by index[E] along dim 0; rows nobody writes are 0.
  * mean divides by max(count,1); max also writes arg_out[dim_size, C] (int64, E where untouched) if non-NULL. */

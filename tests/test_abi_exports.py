@@ -15,14 +15,14 @@ def test_library_exports_every_declared_symbol():
             "mtmc_scatter_add", "mtmc_scatter_mean", "mtmc_scatter_max", "mtmc_mlp_layer_forward",
             "mtmc_postprocess", "mtmc_postprocess_workspace_bytes", "mtmc_cross_entropy_forward",
             "mtmc_cross_entropy_backward", "mtmc_mpn_backward_steps", "mtmc_linear_raw", "mtmc_edge_confusion",
-            "mtmc_linear_presplit_raw", "mtmc_cross_entropy_steps_forward", "mtmc_cross_entropy_steps_backward"} <= declared
+            "mtmc_linear_presplit_raw", "mtmc_mpn_plan_call", "mtmc_cross_entropy_steps_forward", "mtmc_cross_entropy_steps_backward"} <= declared
     assert os.path.exists(_lib.LIB_PATH), "run `python -m mtmc_mpn.build` (or __graft_entry__.build()) first"
     lib = ctypes.CDLL(_lib.LIB_PATH)
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing
     assert set(_lib.EXPORTS) <= declared
     lib.mtmc_mpn_abi_version.restype = ctypes.c_int32
-    assert lib.mtmc_mpn_abi_version() == 3
+    assert lib.mtmc_mpn_abi_version() == 4
 
 
 def test_workspace_sizing_needs_no_gpu():

@@ -1,0 +1,157 @@
+"""Dispatch regimes the kernel selection creates, each against the oracle (SURVEY.md 8(d) config 2b and friends).
+
+The tracker-scale S02 graph -- cams 250/221/281/250 (the reference's misc/mtsc_BUPT21 counts for c007/c008, 250 for the
+two cameras whose files are not shipped) in ONE graph, as `bs_test = 2000` makes it (main.py:86, inference.py:407-413):
+N = 1002, E = 751 202 -- is the one place where FEW node rows (64x64-tile, split-K encoder plan) meet MANY edges
+(> 524 288: four edges per thread in passes A/B, e' never stored, the matrix-core pass C with the walk launched behind it).
+On top of it, the same graph
+  * with a seeded edge permutation: rows unsorted above 524 288 edges -> the matrix-core kernel returns at once on the
+    device-side flag and the half-wave walk does every round;
+  * with nodes interleaved over the cameras, i.e. the TRAINING order (train.py:295-302, :323-329): rows sorted inside
+    each camera block only;
+  * in deterministic mode (fixed-order aggregation; bitwise repeatable h).
+Tolerance: 1e-4 on the logits (north_star), labels equal outside the 2e-4 margin guard, h within 1e-4 relative.
+"""
+import copy
+import types
+
+import pytest
+import torch
+
+import mtmc_mpn
+from golden_util import ARCH
+from mtmc_mpn import _lib, engine, graphs
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL, MARGIN_GUARD = 1e-4, 2e-4
+
+
+def _build(cam_of_node=None, seed=2):
+    """camera_graph with the 16 KB-per-edge attribute gathers done on the device (inputs are inputs: the oracle gets the
+    same tensors)."""
+    import torch.nn.functional as F
+    if cam_of_node is None:
+        cam_of_node = torch.repeat_interleave(torch.arange(4), torch.tensor(list(graphs.S02_TRACKER_CAMS)))
+    n = cam_of_node.numel()
+    x = F.normalize(torch.randn(n, 2048, generator=torch.Generator().manual_seed(seed)), p=2, dim=0)
+    ei = graphs.camera_edge_index(cam_of_node).contiguous()
+    ea = graphs.appearance_edge_attr(x.cuda(), ei.cuda()).cpu()
+    return types.SimpleNamespace(x=x, edge_index=ei, edge_attr=ea)
+
+
+@pytest.fixture(scope="module")
+def tracker():
+    d = _build()
+    assert d.x.shape[0] == 1002 and d.edge_index.shape[1] == 751_202
+    assert bool((d.edge_index[0][1:] >= d.edge_index[0][:-1]).all())       # inference order: rows non-decreasing
+    return d
+
+
+def _model(L, Cs=1, **over):
+    torch.manual_seed(0)
+    params = mtmc_mpn.default_params(num_enc_steps=L, num_class_steps=Cs, **over)
+    m = mtmc_mpn.MOTMPNet(copy.deepcopy(params), None, ARCH).eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    return m, sd, params
+
+
+def _oracle(sd, params, d, dtype=torch.float64):
+    from oracle import mpn_oracle
+    with torch.no_grad():
+        out, h = mpn_oracle.forward(sd, copy.deepcopy(params), ARCH, d.x, d.edge_index, d.edge_attr, dtype=dtype)
+    return out["classified_edges"], h
+
+
+def _gpu(m, d, transposed_view=True):
+    ei = d.edge_index.t().contiguous().cuda().t() if transposed_view else d.edge_index.cuda()
+    with torch.no_grad():
+        out, h = m(types.SimpleNamespace(x=d.x.cuda(), edge_index=ei, edge_attr=d.edge_attr.cuda()))
+    torch.cuda.synchronize()
+    return [t.cpu() for t in out["classified_edges"]], h.cpu()
+
+
+def _check(got, h, want64, h64, tag):
+    for i, (g, w) in enumerate(zip(got, want64)):
+        err = (g.double() - w).abs().max().item()
+        assert err <= LOGIT_TOL, f"{tag}[{i}]: max |dlogit| {err:.3e}"
+        margin = w[:, 1] - w[:, 0]
+        guard = margin.abs() > MARGIN_GUARD
+        flips = int((((g[:, 1] - g[:, 0]) > 0) != (margin > 0))[guard].sum())
+        assert flips == 0, f"{tag}[{i}]: {flips} label flips outside the margin guard"
+    scale = max(1.0, h64.abs().max().item())
+    assert (h.double() - h64).abs().max().item() <= 1e-4 * scale, tag
+
+
+@pytest.mark.parametrize("L,Cs", [(1, 1), (3, 1), (3, 3)])
+def test_tracker_scale_s02_against_fp64_oracle(tracker, L, Cs):
+    """SURVEY 8(d) config 2b at the shipped L = 1 and at the metric's L = 3 (and every step classified)."""
+    m, sd, params = _model(L, Cs)
+    plan = engine.ForwardEngine(m).plan(1002, 751_202)
+    assert plan.pass_c == _lib.PASS_C_MFMA_SORTED and plan.lazy_edges and plan.edges_per_thread == 4
+    assert plan.enc_kernel[0] == _lib.GEMM_INLOOP_64 and plan.enc_split_k[1] == 4       # the regime this test is for
+    got, h = _gpu(m.cuda(), tracker)
+    want64, h64 = _oracle(sd, params, tracker)
+    assert len(got) == Cs
+    _check(got, h, want64, h64, f"tracker L={L} Cs={Cs}")
+    # ... and no further from fp64 than the fp32 reference path itself (x4 slack), as for the fixtures
+    want32, _ = _oracle(sd, params, tracker, torch.float32)
+    ref_err = (want32[-1].double() - want64[-1]).abs().max().item()
+    err = (got[-1].double() - want64[-1]).abs().max().item()
+    assert err <= max(4 * ref_err, 2e-5), f"|gpu - fp64| {err:.2e} vs the fp32 reference's own {ref_err:.2e}"
+
+
+@pytest.mark.parametrize("agg", ["sum", "mean"])
+def test_unsorted_rows_above_524288_edges(tracker, agg):
+    """A seeded permutation of the 751 202 edges: prep_kernel flags the rows as unsorted, pass_c_mfma_kernel returns at
+    once and pass_c_kernel (the walk, atomics per short run) does every round.  Logits must match the sorted run's after
+    un-permuting (G7's property, at a size that takes the many-edge kernels) and the oracle on the permuted list."""
+    m, sd, params = _model(3, 1, node_agg_fn=agg)
+    m = m.cuda()
+    sorted_logits, sorted_h = _gpu(m, tracker)
+    perm = torch.randperm(tracker.edge_index.shape[1], generator=torch.Generator().manual_seed(11))
+    d = types.SimpleNamespace(x=tracker.x, edge_index=tracker.edge_index[:, perm].contiguous(), edge_attr=tracker.edge_attr[perm])
+    assert not bool((d.edge_index[0][1:] >= d.edge_index[0][:-1]).all())
+    got, h = _gpu(m, d, transposed_view=False)
+    want64, h64 = _oracle(sd, params, d)
+    _check(got, h, want64, h64, f"permuted {agg}")
+    assert (got[0] - sorted_logits[0][perm]).abs().max().item() <= 2e-5       # same graph, same answer per edge
+    assert (h - sorted_h).abs().max().item() <= 1e-4 * max(1.0, sorted_h.abs().max().item())
+
+
+def test_training_order_rows_block_sorted_at_tracker_scale():
+    """Nodes ordered by identity, cameras interleaved (train.py:295-302): the edge list is a concatenation of per-camera
+    blocks (train.py:323-329), rows ascending inside a block only -- unsorted for the kernels, with long sorted runs."""
+    cam = torch.arange(1002) % 4
+    d = _build(cam_of_node=cam, seed=7)
+    row = d.edge_index[0]
+    assert d.edge_index.shape[1] > 524_288 and not bool((row[1:] >= row[:-1]).all())
+    m, sd, params = _model(3, 3)
+    got, h = _gpu(m.cuda(), d)
+    want64, h64 = _oracle(sd, params, d)
+    _check(got, h, want64, h64, "training order")
+
+
+def test_deterministic_mode_above_524288_edges(tracker):
+    """MTMC_F_DETERMINISTIC on a many-edge sorted list: per-chunk partials + agg_fixup_kernel instead of float atomics.
+    h and the logits must be BITWISE equal between runs, and right."""
+    m, sd, params = _model(3, 1)
+    m = m.cuda()
+    m.deterministic = True
+    assert engine.ForwardEngine(m).plan(1002, 751_202, flags=_lib.F_DETERMINISTIC).pass_c == _lib.PASS_C_WALK
+    got1, h1 = _gpu(m, tracker)
+    got2, h2 = _gpu(m, tracker)
+    assert torch.equal(h1, h2) and torch.equal(got1[0], got2[0])
+    want64, h64 = _oracle(sd, params, tracker)
+    _check(got1, h1, want64, h64, "deterministic")
+    m.deterministic = False
+    got3, h3 = _gpu(m, tracker)
+    assert (h3 - h1).abs().max().item() <= 1e-5 * max(1.0, h1.abs().max().item())
+
+
+def test_max_aggregation_and_reattach_at_tracker_scale(tracker):
+    """The variants that stay on the walk / the MODE 2-3 pass A, at a many-edge size (fixtures cover them at <= 150k)."""
+    for over in (dict(node_agg_fn="max"), dict(reattach_initial_edges=True, reattach_initial_nodes=True)):
+        m, sd, params = _model(2, 2, **over)
+        got, h = _gpu(m.cuda(), tracker)
+        want64, h64 = _oracle(sd, params, tracker)
+        _check(got, h, want64, h64, str(over))

@@ -92,3 +92,68 @@ def test_opcheck_schema_and_fake():
     key = torch_ops.config_key(m.model_params, m.arch)
     torch.library.opcheck(torch.ops.mtmc_mpn.mp_forward, (x, ei, ea, engine.ordered_params(m), key, False, 0, 0, False),
                           test_utils=("test_schema", "test_faketensor"))
+
+
+def test_encode_nodes_refuses_parameters_it_cannot_hand_to_the_kernels():
+    """Every pointer of `params` reaches the GEMM kernels as is: CPU, half-precision, strided or wrongly shaped tensors
+    must raise BEFORE any library call (they would be wild reads on the device)."""
+    c = Case("g1_random_L1")
+    m, d = c.model().cuda(), c.graph()
+    key = torch_ops.config_key(m.model_params, m.arch)
+    x = d.x.cuda()
+    good = engine.ordered_params(m)[:16]
+
+    def with_(i, t):
+        p = list(good)
+        p[i] = t
+        return p
+    bad = [with_(0, good[0].detach().cpu()),                       # host pointer
+           with_(1, good[1].detach().half()),                      # wrong dtype
+           with_(0, good[0].detach().t().contiguous().t()),        # right shape, strided
+           with_(4, good[4].detach()[:, :-32].contiguous()),       # layer 1 weight [512, 992]
+           with_(2, good[2].detach()[:-1].contiguous())]           # gamma one short
+    for p in bad:
+        with pytest.raises(RuntimeError):
+            torch.ops.mtmc_mpn.encode_nodes(x, p, key)
+    with pytest.raises(RuntimeError):
+        torch.ops.mtmc_mpn.encode_nodes(x.double(), good, key)
+    torch.cuda.synchronize()
+    assert torch.isfinite(torch.ops.mtmc_mpn.encode_nodes(x, good, key)).all()      # the device is still healthy
+
+
+def test_scatter_ops_refuse_an_index_on_another_device():
+    src = torch.randn(100, 4, device="cuda")
+    idx_cpu = torch.randint(0, 10, (100,))
+    for op in (torch.ops.mtmc_mpn.scatter_add, torch.ops.mtmc_mpn.scatter_mean, torch.ops.mtmc_mpn.scatter_max):
+        with pytest.raises(RuntimeError):
+            op(src, idx_cpu, 0, 10)
+    with pytest.raises(RuntimeError):
+        torch.ops.mtmc_mpn.scatter_add(src, torch.rand(100, device="cuda"), 0, 10)    # float "index"
+    torch.cuda.synchronize()
+
+
+def test_a_replaced_parameter_is_the_one_used_and_the_one_that_gets_the_gradient():
+    """The module re-reads its parameters on every call: after a forward, swap in a new Parameter object (what
+    load_state_dict(assign=True) or `layer.weight = nn.Parameter(...)` do) -- the next forward must compute with it and
+    backward must deliver the gradient to it, not to the tensor the first call saw."""
+    c = Case("g3_cams324_L2")
+    m = c.model().cuda().eval()
+    _, x, ei, ea = _inputs(c)
+    data = types.SimpleNamespace(x=x, edge_index=ei, edge_attr=ea)
+    with torch.no_grad():
+        first = m(data)[0]["classified_edges"][-1].clone()
+    cls = m.classifier.edge_mlp.fc_layers[0]
+    old = cls.bias
+    cls.bias = torch.nn.Parameter(old.detach() + 1.0)
+    with torch.no_grad():
+        second = m(data)[0]["classified_edges"][-1]
+    assert (second - first - 1.0).abs().max().item() <= 1e-5         # the classifier bias shifts every logit by exactly 1
+    sd = {k: v.detach().clone() + 0.25 for k, v in m.state_dict().items() if k.endswith("fc_layers.0.bias") and "classifier" in k}
+    m.load_state_dict(sd, strict=False, assign=True)
+    with torch.no_grad():
+        third = m(data)[0]["classified_edges"][-1]
+    assert (third - second - 0.25).abs().max().item() <= 1e-5
+    out = m(data)[0]["classified_edges"][-1]
+    out.sum().backward()
+    assert cls.bias.grad is not None and old.grad is None
+    assert torch.allclose(cls.bias.grad, torch.full_like(cls.bias, float(out.shape[0])))

@@ -1,0 +1,73 @@
+"""mtmc_mpn_plan_call (host-only): a SHARD of a big graph must take the kernels the whole graph takes.
+
+Round 2's pass-C dispatch divided the LOCAL edge count by the GLOBAL node count, so the 8-way partition of BASELINE
+config 5 (12.5 M edges per rank, 1 M nodes) silently fell back from the matrix-core pass C to the half-wave walk -- on
+exactly the run north_star asks to scale.  Results are identical either way, so only a plan query can see it.  No GPU
+needed: the query launches nothing and reads no pointer of the call."""
+import copy
+
+import pytest
+
+import mtmc_mpn
+from mtmc_mpn import _lib, distributed as mdist, engine
+
+
+@pytest.fixture(scope="module")
+def eng():
+    params = mtmc_mpn.default_params(num_enc_steps=3, num_class_steps=1)
+    return engine.ForwardEngine(mtmc_mpn.MOTMPNet(copy.deepcopy(params), None, "resnet101").eval())
+
+
+N5, E5 = 1_000_000, 100_000_000          # BASELINE config 5
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_config5_shards_take_the_whole_graphs_kernels(eng, world):
+    whole = eng.plan(N5, E5)
+    assert whole.pass_c == _lib.PASS_C_MFMA_SORTED and whole.lazy_edges and whole.edges_per_thread == 4
+    assert whole.enc_kernel[0] == _lib.GEMM_PRESPLIT_256 and whole.enc_kernel[1] == _lib.GEMM_INLOOP_128
+    rows = mdist.even_ranges(N5, world)
+    edges = mdist.even_ranges(E5, world)
+    for r in range(world):
+        e_loc = edges[r][1] - edges[r][0]
+        # row-complete shard (bench.py --gpus N: row-sorted list, boundaries snapped to row changes, own_rows)
+        own = eng.plan(N5, e_loc, E5, node_range=rows[r], row_range=rows[r])
+        assert own.avg_degree == pytest.approx(100.0, rel=1e-6)
+        # general shard (node state all-reduced, every rank projects every node)
+        gen = eng.plan(N5, e_loc, E5, node_range=rows[r])
+        assert gen.avg_degree == pytest.approx(100.0)
+        for p in (own, gen):
+            assert p.pass_c == whole.pass_c, f"rank {r}/{world} left the matrix-core pass C"
+            assert p.lazy_edges == whole.lazy_edges and p.edges_per_thread == whole.edges_per_thread
+            assert p.enc_kernel[:3] == whole.enc_kernel[:3] and p.enc_split_k == whole.enc_split_k
+
+
+def test_row_complete_shard_is_judged_on_its_own_rows(eng):
+    # a rank whose rows have few out-edges must NOT be sent to the matrix-core kernel just because the graph's mean is high
+    p = eng.plan(100_000, 600_000, 10_000_000, node_range=(0, 50_000), row_range=(0, 50_000))
+    assert p.avg_degree == pytest.approx(12.0) and p.pass_c == _lib.PASS_C_WALK
+    # ... and an empty row range plans without dividing by zero
+    p = eng.plan(100_000, 0, 10_000_000, node_range=(0, 0), row_range=(7, 7))
+    assert p.avg_degree == 0.0 and p.pass_c == _lib.PASS_C_WALK
+
+
+def test_single_gpu_regimes(eng):
+    s02 = eng.plan(450, 150_454)                       # headline graph: few rows, few edges
+    assert s02.enc_kernel == [_lib.GEMM_INLOOP_64] * 4 and s02.enc_split_k[:3] == [4, 4, 4] and s02.enc_split_k[3] == 1
+    assert s02.pass_c == _lib.PASS_C_MFMA_ANY and not s02.lazy_edges and s02.edges_per_thread == 1
+    trk = eng.plan(1002, 751_202)                      # few rows AND more than 524288 edges
+    assert trk.enc_kernel == [_lib.GEMM_INLOOP_64] * 4 and trk.enc_split_k == [1, 4, 4, 1]   # 256 tiles in layer 0: unsplit
+    assert trk.pass_c == _lib.PASS_C_MFMA_SORTED and trk.lazy_edges and trk.edges_per_thread == 4
+    cfg4 = eng.plan(100_000, 10_000_000)
+    assert cfg4.enc_kernel[0] == _lib.GEMM_PRESPLIT_256 and cfg4.pass_c == _lib.PASS_C_MFMA_SORTED
+    det = eng.plan(100_000, 10_000_000, flags=_lib.F_DETERMINISTIC)
+    assert det.pass_c == _lib.PASS_C_WALK               # fixed-order aggregation lives in the walk
+    trn = eng.plan(440, 180_000, training=True)
+    assert trn.pass_c == _lib.PASS_C_WALK and not trn.lazy_edges     # Dropout in the node update; e' kept for the tape
+
+
+def test_plan_rejects_inconsistent_ranges(eng):
+    with pytest.raises(RuntimeError):
+        eng.plan(100, 50, 10)                           # more local edges than the graph has
+    with pytest.raises(RuntimeError):
+        eng.plan(100, 50, node_range=(10, 200))

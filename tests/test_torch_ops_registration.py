@@ -55,6 +55,59 @@ def test_shape_inference_under_fake_tensors():
         assert v.shape == (50, 32) and a.dtype == torch.int64
 
 
+def test_fake_tape_has_the_real_tapes_size_and_backward_declares_the_mutation():
+    """Under FakeTensorMode / torch.compile the op must describe itself truthfully: with tape=True the third output is
+    the training workspace (mtmc_mpn_train_workspace_bytes + 256 bytes, as the real op allocates it), and mp_backward
+    writes into it (scratch + one memset), which its schema declares."""
+    import ctypes as C
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from mtmc_mpn import _lib
+    m, key = _model(L=2, Cs=2)
+    params = engine.ordered_params(m)
+    eng = torch_ops.engine_for(key)
+    model = eng.shape_model()
+    want = _lib.load().mtmc_mpn_train_workspace_bytes(C.byref(model), 50, 700) + 256
+    assert want > 256
+    # the placeholder-pointer struct sizes exactly like the one filled from real tensors
+    real = engine.ForwardEngine(m).model_struct(torch.device("cpu"))
+    assert _lib.load().mtmc_mpn_train_workspace_bytes(C.byref(real), 50, 700) + 256 == want
+    with FakeTensorMode(allow_non_fake_inputs=True) as mode:
+        x, ei, ea = torch.empty(50, 2048), torch.empty(2, 700, dtype=torch.int64), torch.empty(700, 2)
+        fp = [mode.from_tensor(p.detach()) for p in params]
+        _, _, tape = torch.ops.mtmc_mpn.mp_forward(x, ei, ea, fp, key, True, 1, 0, True)
+        assert tape.dtype == torch.uint8 and tape.numel() == want
+    schema = str(torch.ops.mtmc_mpn.mp_backward.default._schema)
+    assert "Tensor(a!) tape" in schema
+
+
+def test_module_rereads_its_parameters_on_every_call():
+    """A Parameter object replaced after construction (load_state_dict(assign=True), manual assignment, ...) must be
+    the tensor the op receives: the flat list is rebuilt from the module tree per call, never cached."""
+    m, _ = _model()
+    before = engine.ordered_params(m)
+    lin = m.encoder.node_mlp.fc_layers[0]
+    lin.weight = torch.nn.Parameter(torch.zeros_like(lin.weight))
+    after = engine.ordered_params(m)
+    assert after[0] is lin.weight and after[0] is not before[0]
+    eng = engine.ForwardEngine(m)
+    assert eng.params()[0] is lin.weight
+    m.classifier.edge_mlp.fc_layers[0].bias = torch.nn.Parameter(torch.ones(2))
+    assert eng.params()[-1] is m.classifier.edge_mlp.fc_layers[0].bias
+
+
+def test_layout_queries_refuse_a_corrupt_layer_count():
+    import ctypes as C
+    from mtmc_mpn import _lib
+    m, _ = _model()
+    model = engine.ForwardEngine(m).model_struct(torch.device("cpu"))
+    model.n_enc_layers = 99                                   # would index enc_node[] / the offset array out of bounds
+    assert _lib.load().mtmc_mpn_grad_layout(C.byref(model), None, 0) == 0
+    call = _lib.Call()
+    buf = (C.c_float * 4)()
+    rc = _lib.load().mtmc_mpn_backward_flat(C.byref(model), C.byref(call), None, None, buf, 4, None, None)
+    assert rc == _lib.E_ARG
+
+
 def test_python_and_c_agree_on_the_gradient_layout():
     import ctypes as C
     from mtmc_mpn import _lib
