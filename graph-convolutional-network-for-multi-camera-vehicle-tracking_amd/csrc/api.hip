@@ -82,9 +82,10 @@ int32_t mtmc_mpn_plan_call(const mtmc_mpn_model* model, const mtmc_mpn_call* cal
     mtmc::gemm_plan(c->n_nodes, L.in_dim, L.out_dim, &sk_full);
     const int cfg = rows > 0 ? mtmc::gemm_plan(rows, L.in_dim, L.out_dim, &sk_here) : 0;
     const bool slab = sk_here > 1 && (size_t)sk_here * rows <= (size_t)(sk_full > 1 ? sk_full : 0) * c->n_nodes;   // run_phase
-    out->enc_kernel[l] = (l == 0 && pre0) ? MTMC_GEMM_PRESPLIT_256 : cfg == 2 ? MTMC_GEMM_INLOOP_128 : cfg == 1 ? MTMC_GEMM_INLOOP_64
+    const bool stg = l >= 1 && !c->training && mtmc::staged_layer(c->n_nodes, L.in_dim, L.out_dim) && mtmc::staged_layer(rows, L.in_dim, L.out_dim);
+    out->enc_kernel[l] = (l == 0 && pre0) ? MTMC_GEMM_PRESPLIT_256 : stg ? MTMC_GEMM_STAGED_128 : cfg == 2 ? MTMC_GEMM_INLOOP_128 : cfg == 1 ? MTMC_GEMM_INLOOP_64
                                                                                                            : MTMC_GEMM_GENERIC;
-    out->enc_split_k[l] = ((l == 0 && pre0) || !slab) ? 1 : sk_here;
+    out->enc_split_k[l] = ((l == 0 && pre0) || stg || !slab) ? 1 : sk_here;
   }
   out->edges_per_thread = mtmc::plan_edges_per_thread(c->n_edges);
   out->lazy_edges = lazy_edges(c) ? 1 : 0;

@@ -38,6 +38,8 @@ struct Layout {
   std::vector<size_t> z_tr, e_tr, h_tr;       // per round: z1 [E][4], e' [E][4], aggregated h [N][32]
   std::vector<size_t> P_tr, Q_tr;             // per round: the node projections [2][N][4], [N][32]
   size_t xh, inv_a, wh, inv_w; bool presplit0;   // layer 0 on pre-split operands (many-row graphs): fp16 planes + row scales
+  size_t wh_l[MTMC_MAX_ENC_LAYERS], inv_w_l[MTMC_MAX_ENC_LAYERS]; bool staged[MTMC_MAX_ENC_LAYERS];   // layers >= 1 on the
+                                               // role-split kernel (gemm_staged.hip): the layer's weight planes + row scales
   size_t g_e[2], g_e0, g_h[2], g_h0, g_P, g_Q, g_de2, g_arg;   // gradients wrt e_r, e0, h_r, h0, P, Q; A^T dz2 [E][4]
   size_t bst;                                  // f64[2L+1][kStatRep][kBwdStride] backward statistics blocks
   size_t bwd_zero, bwd_zero_end;               // the range the backward clears with one memset
@@ -127,6 +129,13 @@ inline void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* l
     lo->inv_a = take((size_t)N * sizeof(float));
     lo->wh = take((size_t)2 * O0 * K0 * sizeof(uint16_t));
     lo->inv_w = take(O0 * sizeof(float));
+  }
+  for (int l = 1; l < m->n_enc_layers; ++l) {
+    lo->staged[l] = !training && mtmc::staged_layer(N, m->enc_node[l].in_dim, m->enc_node[l].out_dim);
+    if (lo->staged[l]) {
+      lo->wh_l[l] = take((size_t)2 * m->enc_node[l].out_dim * m->enc_node[l].in_dim * sizeof(uint16_t));
+      lo->inv_w_l[l] = take((size_t)m->enc_node[l].out_dim * sizeof(float));
+    }
   }
   if (training) {
     for (int r = 0; r < L; ++r) {
@@ -303,6 +312,11 @@ inline bool use_presplit0(const Ctx& x) {
   return x.lo.presplit0 && mtmc::presplit_layer0(x.c->node_hi - x.c->node_lo, x.m->enc_node[0].in_dim, x.m->enc_node[0].out_dim);
 }
 
+// layer l >= 1 on the role-split kernel: the layout has its weight planes AND this call's rows are many too
+inline bool use_staged(const Ctx& x, int l) {
+  return l >= 1 && x.lo.staged[l] && mtmc::staged_layer(x.c->node_hi - x.c->node_lo, x.m->enc_node[l].in_dim, x.m->enc_node[l].out_dim);
+}
+
 enum { kPhMemset = -1, kPhPrep = -2 };   // the two halves of MTMC_PH_BEGIN, for the forked forward
 
 inline const int* scale_deg(const Ctx& x) {   // the degree mean aggregation divides by
@@ -334,8 +348,9 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
         if (c->node_hi > c->node_lo) {
           if (!pre0) p.jobs[p.n_jobs++] = {c->x, c->node_hi - c->node_lo, m->enc_node[0].in_dim, c->x_row_stride, amax, 0, 0};
           for (int l = pre0 ? 1 : 0; l < m->n_enc_layers; ++l)
-            p.jobs[p.n_jobs++] = {m->enc_node[l].weight, m->enc_node[l].out_dim, m->enc_node[l].in_dim,
-                                  m->enc_node[l].in_dim, amax + (1 + l) * mtmc::kAmaxRep, 0, 0};
+            if (!use_staged(x, l))              // (a staged layer's weights are split into planes below instead)
+              p.jobs[p.n_jobs++] = {m->enc_node[l].weight, m->enc_node[l].out_dim, m->enc_node[l].in_dim,
+                                    m->enc_node[l].in_dim, amax + (1 + l) * mtmc::kAmaxRep, 0, 0};
         }
         mtmc::launch_prep(p, s);
         if (pre0) {     // instead of the |.|max of x and W0: their fp16 planes and row scales (one pass over each)
@@ -344,6 +359,11 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
           mtmc::launch_split_rows(m->enc_node[0].weight, m->enc_node[0].in_dim, m->enc_node[0].out_dim,
                                   m->enc_node[0].in_dim, x.at<void>(x.lo.wh), x.at<float>(x.lo.inv_w), s);
         }
+        if (c->node_hi > c->node_lo)
+          for (int l = 1; l < m->n_enc_layers; ++l)
+            if (use_staged(x, l))
+              mtmc::launch_split_rows(m->enc_node[l].weight, m->enc_node[l].in_dim, m->enc_node[l].out_dim,
+                                      m->enc_node[l].in_dim, x.at<void>(x.lo.wh_l[l]), x.at<float>(x.lo.inv_w_l[l]), s);
       }
       break;
     }
@@ -370,6 +390,23 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
         // 100000 x 2048 x 1024 on one box -- fewer joules per flop at the power cap this GEMM runs at
         const int rc = mtmc::launch_gemm_presplit(q, s, 11);
         if (rc != 0) return fail(rc == MTMC_E_HIP ? MTMC_E_HIP : MTMC_E_ARG, "encoder layer 0: pre-split GEMM refused the shape or the launch");
+        break;
+      }
+      if (use_staged(x, arg)) {
+        if (phase == MTMC_PH_NODE_COMBINE) break;                // never split along K
+        unsigned* amax = x.at<unsigned>(x.lo.amax);
+        mtmc::StagedGemmParams q;
+        q.A = x.at<float>(x.lo.Y[arg - 1]); q.lda = m->enc_node[arg - 1].out_dim;
+        q.stats_in = x.at<double>(x.lo.stat_enc_layer[arg - 1]);
+        q.gamma_in = m->enc_node[arg - 1].gamma; q.beta_in = m->enc_node[arg - 1].beta; q.count = (double)c->n_nodes;
+        q.amax_a = amax + (1 + MTMC_MAX_ENC_LAYERS + (arg - 1)) * mtmc::kAmaxRep;
+        q.Wh = x.at<_Float16>(x.lo.wh_l[arg]); q.inv_w = x.at<float>(x.lo.inv_w_l[arg]);
+        q.bias = Lr.bias; q.Y = x.at<float>(x.lo.Y[arg]); q.ldy = Lr.out_dim;
+        q.stats_out = x.at<double>(x.lo.stat_enc_layer[arg]);
+        q.amax_y = amax + (1 + MTMC_MAX_ENC_LAYERS + arg) * mtmc::kAmaxRep;
+        q.M = rows; q.K = Lr.in_dim; q.Nout = Lr.out_dim;
+        const int rc = mtmc::launch_gemm_staged(q, s);
+        if (rc != 0) return fail(rc == MTMC_E_HIP ? MTMC_E_HIP : MTMC_E_ARG, "encoder layer %d: role-split GEMM refused the shape or the launch", arg);
         break;
       }
       mtmc::GemmParams g;

@@ -126,35 +126,52 @@ __global__ __launch_bounds__(256) void enc2_kernel(EdgeEncParams enc, const floa
 // z1 of one edge: Pr[row] + Pc[col] + We_e . e_in + be
 // ------------------------------------------------------------------------------------------------
 // The small constants every edge needs in pass A -- the two edge-encoder layers with their BatchNorm affines (first round /
-// reattached edges: e0 is recomputed from the 8-byte attributes, never stored) and the edge-update weights.  Up to 84
-// floats: as uniform (scalar) operands they did not fit the SGPR file (105-160 spills, each a v_readlane in the loop; the
-// first round's launch took 220 us at config 4 against 133 us for the later rounds, which move MORE bytes).  They are
-// staged once per workgroup in LDS and read back by every lane into VECTOR registers: a load from LDS lands in a VGPR
-// and stays there.  Same arithmetic, same order as edge_enc_hidden / edge_enc_out (common.h).
-struct EdgeConsts {
-  float w1[4][2], b1[4], s1[4], t1[4];     // hidden layer (second column 0 when edge_in_dim == 1)
-  float w2[4][4], b2[4], s2[4], t2[4];     // output layer
-  float uw[4][8], ub[4];                   // edge update: the e columns of We (first 4: e0 when reattached, else e), bias
+// reattached edges: e0 is recomputed from the 8-byte attributes, never stored) and the edge-update weights: 68 floats in
+// the first round, 84 with reattached edges.  As uniform (scalar) operands they did not all fit the SGPR file (105-160
+// spills, each a v_readlane in the loop: the first round's launch took 220 us at config 4 against 133 us for the later
+// rounds, which move MORE bytes); all in vector registers they cost two waves per SIMD of occupancy.  So they are SPLIT:
+// the hidden layer (20 floats) and, without reattached edges, the 4 x 4 update weights (20) stay scalar -- read through
+// uniform pointers --, the output layer (28) and the 4 x 8 update weights of the reattached forms (36) are staged once per
+// workgroup in LDS and read back by every lane: a load from LDS lands in a VGPR and stays there.
+// Same arithmetic, same order as edge_enc_hidden / edge_enc_out (common.h).
+struct EdgeConstsV {                       // the LDS-staged (vector-register) part
+  float w2[4][4], b2[4], s2[4], t2[4];     // output layer of the edge encoder
+  float uw[4][8], ub[4];                   // reattached forms only: [W_e0 | W_e] columns of the edge update, bias
 };
-constexpr int kEdgeConstsN = sizeof(EdgeConsts) / sizeof(float);
+constexpr int kEdgeConstsV = sizeof(EdgeConstsV) / sizeof(float);
+struct EdgeConstsS {                       // the scalar part: copied out of memory ONCE, before the edge loop -- read through
+  float w1[4][2], b1[4], s1[4], t1[4];     // the parameter pointers inside the loop they would be re-fetched after every z1
+  float uw[4][4], ub[4];                   // store (which may alias them as far as the compiler knows)
+};
+template <int MODE>
+__device__ __forceinline__ void load_edge_consts_s(const RoundParams& p, EdgeConstsS& k) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    k.w1[i][0] = MODE != 0 ? p.enc.w1[i * p.enc.fe] : 0.f;
+    k.w1[i][1] = (MODE != 0 && p.enc.fe > 1) ? p.enc.w1[i * p.enc.fe + 1] : 0.f;
+    k.b1[i] = MODE != 0 ? p.enc.b1[i] : 0.f;
+    k.s1[i] = MODE != 0 ? p.enc.aff[i] : 0.f;            // p.enc.aff = s1[4] | t1[4] | s2[4] | t2[4] (EdgeEncAffine)
+    k.t1[i] = MODE != 0 ? p.enc.aff[4 + i] : 0.f;
+    k.ub[i] = (MODE & 2) ? 0.f : p.ue_b[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k.uw[i][j] = (MODE & 2) ? 0.f : p.ue_w[i * p.ue_ld + p.ue_eoff + j];
+  }
+}
 
 // whole block; ends with a barrier.  MODE as in pass_a_kernel.
 template <int MODE>
-__device__ __forceinline__ void stage_edge_consts(const RoundParams& p, EdgeConsts* cs) {
+__device__ __forceinline__ void stage_edge_consts(const RoundParams& p, EdgeConstsV* cs) {
   float* dst = reinterpret_cast<float*>(cs);
-  for (int i = threadIdx.x; i < kEdgeConstsN; i += blockDim.x) {
-    float v = 0.f;
-    if (i < 8) { const int k = i >> 1, j = i & 1; v = (MODE != 0 && j < p.enc.fe) ? p.enc.w1[k * p.enc.fe + j] : 0.f; }
-    else if (i < 12) v = MODE != 0 ? p.enc.b1[i - 8] : 0.f;
-    else if (i < 20) v = MODE != 0 ? p.enc.aff[i - 12] : 0.f;                    // s1[4] | t1[4] of EdgeEncAffine
-    else if (i < 36) v = MODE != 0 ? p.enc.w2[i - 20] : 0.f;
-    else if (i < 40) v = MODE != 0 ? p.enc.b2[i - 36] : 0.f;
-    else if (i < 48) v = MODE != 0 ? p.enc.aff[8 + i - 40] : 0.f;                // s2[4] | t2[4]
-    else if (i < 80) {
-      const int k = (i - 48) >> 3, j = (i - 48) & 7;
-      v = j < ((MODE & 2) ? 8 : 4) ? p.ue_w[k * p.ue_ld + p.ue_eoff + j] : 0.f;
-    } else v = p.ue_b[i - 80];
-    dst[i] = v;
+  if (MODE != 0) {
+    for (int i = threadIdx.x; i < kEdgeConstsV; i += blockDim.x) {
+      float v;
+      if (i < 16) v = p.enc.w2[i];
+      else if (i < 20) v = p.enc.b2[i - 16];
+      else if (i < 28) v = p.enc.aff[8 + i - 20];                                  // s2[4] | t2[4] of EdgeEncAffine
+      else if (i < 60) v = (MODE & 2) ? p.ue_w[((i - 28) >> 3) * p.ue_ld + p.ue_eoff + ((i - 28) & 7)] : 0.f;
+      else v = p.ue_b[i - 60];
+      dst[i] = v;
+    }
   }
   __syncthreads();
 }
@@ -163,69 +180,86 @@ struct PrevAffine { float s[4], t[4]; };   // BatchNorm affine of the previous r
 
 // z1 of one edge: Pr[row] + Pc[col] + We_e . e_in + be.
 // MODE 0: a later round without reattached edges (no attribute loads, no edge-encoder arithmetic, 4 x 4 weights);
-// bit 0: first round, bit 1: reattach_initial_edges
+// bit 0: first round, bit 1: reattach_initial_edges.
+// Loads and arithmetic are separate steps so that a thread's kEPT edges have ALL their loads in flight before the first
+// result is stored (the z1 store may alias every input as far as the compiler can tell: interleaved, each edge's load
+// chain would start only after the previous edge's store).
+struct EdgeIn { float4 pr, pc, ev; float a0, a1; };
+
 template <int MODE>
-__device__ __forceinline__ void edge_z1(const RoundParams& p, const EdgeConsts& c, const PrevAffine& pa, int64_t e, int& r,
-                                        float (&z)[4]) {
-  constexpr bool first_round = (MODE & 1) != 0, reattach = (MODE & 2) != 0;
-  r = p.row32[e];
-  const int col = p.col32[e];
+__device__ __forceinline__ void edge_load(const RoundParams& p, int64_t e, EdgeIn& in) {
+  const int r = p.row32[e], col = p.col32[e];
   // P = [Pr: N x 4 | Pc: N x 4]: the randomly gathered half is a compact 16 B/node table (four nodes per 64-byte sector)
-  const float4 pr = *reinterpret_cast<const float4*>(p.P + (int64_t)r * 4);
-  const float4 pc = *reinterpret_cast<const float4*>(p.P + ((int64_t)p.n_nodes + col) * 4);
+  in.pr = *reinterpret_cast<const float4*>(p.P + (int64_t)r * 4);
+  in.pc = *reinterpret_cast<const float4*>(p.P + ((int64_t)p.n_nodes + col) * 4);
+  in.a0 = in.a1 = 0.f;
+  in.ev = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (MODE != 0) load_attr(p.attr, p.enc.fe, e, in.a0, in.a1);
+  if (!(MODE & 1)) in.ev = reinterpret_cast<const float4*>(p.e_prev)[e];
+}
+
+template <int MODE, bool DROP>
+__device__ __forceinline__ void edge_z1(const RoundParams& p, const EdgeConstsS& ks, const EdgeConstsV& c,
+                                        const PrevAffine& pa, int64_t e, const EdgeIn& in, float (&z)[4]) {
+  constexpr bool first_round = (MODE & 1) != 0, reattach = (MODE & 2) != 0;
   float e0[4] = {0, 0, 0, 0}, ep[4];
   if (first_round || reattach) {
-    float a0, a1, u[4];
-    load_attr(p.attr, p.enc.fe, e, a0, a1);
+    float u[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {                       // edge_enc_hidden
-      const float zz = fmaf(c.w1[k][1], a1, c.b1[k] + c.w1[k][0] * a0);
-      u[k] = drop_apply(p.enc.drop, kDropEncEdge1, (unsigned long long)e * 4 + k, fmaxf(fmaf(zz, c.s1[k], c.t1[k]), 0.f));
+    for (int k = 0; k < 4; ++k) {                       // edge_enc_hidden, scalar operands (edge_in_dim 1: w1[k][1] = a1 = 0)
+      const float zz = fmaf(ks.w1[k][1], in.a1, ks.b1[k] + ks.w1[k][0] * in.a0);
+      u[k] = fmaxf(fmaf(zz, ks.s1[k], ks.t1[k]), 0.f);
+      if (DROP) u[k] = drop_apply(p.enc.drop, kDropEncEdge1, (unsigned long long)e * 4 + k, u[k]);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {                       // edge_enc_out
       float zz = c.b2[k];
 #pragma unroll
       for (int j = 0; j < 4; ++j) zz = fmaf(c.w2[k][j], u[j], zz);
-      e0[k] = drop_apply(p.enc.drop, kDropEncEdge2, (unsigned long long)e * 4 + k, fmaxf(fmaf(zz, c.s2[k], c.t2[k]), 0.f));
+      e0[k] = fmaxf(fmaf(zz, c.s2[k], c.t2[k]), 0.f);
+      if (DROP) e0[k] = drop_apply(p.enc.drop, kDropEncEdge2, (unsigned long long)e * 4 + k, e0[k]);
     }
   }
   if (first_round) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) ep[j] = e0[j];
   } else {
-    const float4 v = reinterpret_cast<const float4*>(p.e_prev)[e];
-    ep[0] = v.x; ep[1] = v.y; ep[2] = v.z; ep[3] = v.w;
+    ep[0] = in.ev.x; ep[1] = in.ev.y; ep[2] = in.ev.z; ep[3] = in.ev.w;
     if (p.lazy_e) {                               // the buffer holds the previous round's z1: e' = relu(bn(z1))
 #pragma unroll
       for (int j = 0; j < 4; ++j) ep[j] = fmaxf(fmaf(ep[j], pa.s[j], pa.t[j]), 0.f);
     }
   }
-  const float prv[4] = {pr.x, pr.y, pr.z, pr.w}, pcv[4] = {pc.x, pc.y, pc.z, pc.w};
+  const float prv[4] = {in.pr.x, in.pr.y, in.pr.z, in.pr.w}, pcv[4] = {in.pc.x, in.pc.y, in.pc.z, in.pc.w};
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    float acc = prv[k] + pcv[k] + c.ub[k];
     if (reattach) {
+      float acc = prv[k] + pcv[k] + c.ub[k];
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc = fmaf(c.uw[k][j], e0[j], acc);
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc = fmaf(c.uw[k][4 + j], ep[j], acc);
-    } else {
+      z[k] = acc;
+    } else {                                            // 4 x 4 weights + bias: scalar operands
+      float acc = prv[k] + pcv[k] + ks.ub[k];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = fmaf(c.uw[k][j], ep[j], acc);
+      for (int j = 0; j < 4; ++j) acc = fmaf(ks.uw[k][j], ep[j], acc);
+      z[k] = acc;
     }
-    z[k] = acc;
   }
 }
 
 // kEPT = edges per thread and loop trip in passes A/B: four independent load chains in flight on big graphs, one on
-// small ones, where filling the 256 CUs with waves matters more (pick_ept)
+// small ones, where filling the 256 CUs with waves matters more (pick_ept).  DROP: the edge encoder's Dropout is compiled
+// in (training); eval-mode kernels carry neither its hash arithmetic nor its scalar operands.
 
-template <int kEPT, int MODE>
-__global__ __launch_bounds__(256) void pass_a_kernel(RoundParams p) {
-  __shared__ EdgeConsts cs_s;
+template <int kEPT, int MODE, bool DROP>
+__global__ __launch_bounds__(256, (MODE == 0 ? 5 : 1)) void pass_a_kernel(RoundParams p) {   // plain later round: <= 96 VGPRs
+  __shared__ EdgeConstsV cs_s;
   __shared__ double red[8 * 4];
   __shared__ PrevAffine pa_s;
+  EdgeConstsS ks;                                  // first thing in the kernel: ahead of every store and barrier these
+  load_edge_consts_s<MODE>(p, ks);                 // uniform loads are scalar loads (SGPRs); behind one they become vector loads
   if (p.lazy_e && !(MODE & 1)) {
     stat_gather(p.prev_stats + kRoundZ1Off, 8, kZ1Stride, red);
     __syncthreads();
@@ -237,38 +271,45 @@ __global__ __launch_bounds__(256) void pass_a_kernel(RoundParams p) {
   PrevAffine pa;
 #pragma unroll
   for (int j = 0; j < 4; ++j) { pa.s[j] = pa_s.s[j]; pa.t[j] = pa_s.t[j]; }
-  EdgeConsts c;                                    // per-lane copy: VGPRs (only the fields MODE uses survive)
+  EdgeConstsV c;                                   // per-lane copy: VGPRs (only the fields MODE uses survive)
   {
     const float* src = reinterpret_cast<const float*>(&cs_s);
     float* dst = reinterpret_cast<float*>(&c);
 #pragma unroll
-    for (int i = 0; i < kEdgeConstsN; ++i) dst[i] = src[i];
+    for (int i = 0; i < kEdgeConstsV; ++i) dst[i] = MODE != 0 ? src[i] : 0.f;
   }
   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x * kEPT;
-  for (int64_t base = (int64_t)blockIdx.x * blockDim.x * kEPT + threadIdx.x; base < p.n_edges; base += stride) {
-    float z[kEPT][4];
+  auto finish = [&](int64_t e, const EdgeIn& in) {
+    float z[4];
+    edge_z1<MODE, DROP>(p, ks, c, pa, e, in, z);
+    // the random 16-byte P[col] gather is what bounds this pass (one cache line per lane): do it once and
+    // hand z1 to pass B through memory instead of gathering again there
+    reinterpret_cast<float4*>(p.e_buf)[e] = make_float4(z[0], z[1], z[2], z[3]);
 #pragma unroll
-    for (int i = 0; i < kEPT; ++i) {
-      const int64_t e = base + i * 256;
-      int r;
-      if (e < p.n_edges) {
-        edge_z1<MODE>(p, c, pa, e, r, z[i]);
-        // the random 16-byte P[col] gather is what bounds this pass (one cache line per lane): do it once and
-        // hand z1 to pass B through memory instead of gathering again there
-        reinterpret_cast<float4*>(p.e_buf)[e] = make_float4(z[i][0], z[i][1], z[i][2], z[i][3]);
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) z[i][k] = 0.f;
-      }
+    for (int k = 0; k < 4; ++k) {
+      acc[k] += z[k];
+      acc[4 + k] += (double)z[k] * z[k];
     }
+  };
+  // whole tiles of 256 * kEPT edges without a bounds check per edge (no exec-mask bookkeeping in the hot loop) ...
+  constexpr int64_t kTile = 256 * kEPT;
+  const int64_t n_full = p.n_edges / kTile;
+  for (int64_t t = blockIdx.x; t < n_full; t += gridDim.x) {
+    const int64_t base = t * kTile + threadIdx.x;
+    EdgeIn in[kEPT];
 #pragma unroll
-    for (int i = 0; i < kEPT; ++i)
+    for (int i = 0; i < kEPT; ++i) edge_load<MODE>(p, base + i * 256, in[i]);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        acc[k] += z[i][k];
-        acc[4 + k] += (double)z[i][k] * z[i][k];
-      }
+    for (int i = 0; i < kEPT; ++i) finish(base + i * 256, in[i]);
+  }
+  // ... and the last, partial tile: one 256-edge piece per block
+  for (int i = blockIdx.x; i < kEPT; i += gridDim.x) {
+    const int64_t e = n_full * kTile + (int64_t)i * 256 + threadIdx.x;
+    if (e < p.n_edges) {
+      EdgeIn in;
+      edge_load<MODE>(p, e, in);
+      finish(e, in);
+    }
   }
   block_atomic_add<8>(acc, p.stats + kRoundZ1Off, kZ1Stride, red);
 }
@@ -828,6 +869,10 @@ static inline int edge_grid(int64_t n_edges, int per_block) {
 // finest decomposition there (measured on camera graphs of 50k..12M edges, tools/size_sweep.py).
 constexpr int64_t kSmallEdges = 2048 * 256;
 static inline int pick_ept(int64_t n_edges) { return n_edges <= kSmallEdges ? 1 : 4; }
+#ifndef MTMC_PASS_A_EPT
+#define MTMC_PASS_A_EPT 4
+#endif
+constexpr int kPassAEpt = MTMC_PASS_A_EPT;
 
 void launch_prep(const PrepParams& p0, hipStream_t s) {
   PrepParams p = p0;
@@ -850,9 +895,13 @@ void launch_enc2(const EdgeEncParams& enc, const float* attr, int64_t n_edges, d
 template <int MODE>
 static void launch_pass_a_mode(const RoundParams& p, hipStream_t s) {
   // (edges per thread 1/2/4/8 x grid caps 1536..16384 swept at config 4: 0.45-0.51 ms for the three launches, flat)
+  if (p.enc.drop.on) {            // training (the encoder's Dropout compiled in): graphs are small, one edge per thread
+    hipLaunchKernelGGL((pass_a_kernel<1, MODE, true>), dim3(edge_grid(p.n_edges, 256)), dim3(256), 0, s, p);
+    return;
+  }
   switch (pick_ept(p.n_edges)) {
-    case 1: hipLaunchKernelGGL((pass_a_kernel<1, MODE>), dim3(edge_grid(p.n_edges, 256)), dim3(256), 0, s, p); break;
-    default: hipLaunchKernelGGL((pass_a_kernel<4, MODE>), dim3(edge_grid(p.n_edges, 1024)), dim3(256), 0, s, p);
+    case 1: hipLaunchKernelGGL((pass_a_kernel<1, MODE, false>), dim3(edge_grid(p.n_edges, 256)), dim3(256), 0, s, p); break;
+    default: hipLaunchKernelGGL((pass_a_kernel<kPassAEpt, MODE, false>), dim3(edge_grid(p.n_edges, 256 * kPassAEpt)), dim3(256), 0, s, p);
   }
 }
 void launch_pass_a(const RoundParams& p, hipStream_t s) {

@@ -622,39 +622,82 @@ __global__ __launch_bounds__(512, 1) void gemm_f16p_m16_kernel(SplitGemmParams p
     multiply(kt & 1);
   }
 
-  // ---- epilogue: a lane holds, per 16 x 16 block, rows 4*(lane/16) .. +3 of column lane%16
+  // ---- epilogue: a lane holds, per 16 x 16 block, rows 4*(lane/16) .. +3 of column lane%16 -- stored as they stand, a
+  // wave-instruction would write four 64-byte row segments (half lines: WRITE_SIZE 1.40 x the bytes of Y at config 4).
+  // The stages are free now: every wave transposes its 16 x 64 strips through a private 4 KB of LDS and writes whole
+  // 256-byte row segments, 16 bytes per lane.  The column statistics are taken from the registers on the way.
   __syncthreads();
-  double* colred = reinterpret_cast<double*>(smem);
+  constexpr int kStgLd = 64;                            // floats per staged row: conflict-free b128 reads (2-way b32 writes: free)
+  float* stg = reinterpret_cast<float*>(smem) + wid * (16 * kStgLd);
+  double* colred = reinterpret_cast<double*>(smem + 8 * 16 * kStgLd * sizeof(float));   // behind the eight staging strips
+  const bool vec_ok = (p.ldy & 3) == 0 && ((uintptr_t)p.Y & 15) == 0;
   float ymax = 0.f;
+  float bias[4], iw[4];
+  double cs[4] = {0, 0, 0, 0}, cq[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int cl = wn * 64 + j * 16 + r16;
-    const int col = n0 + cl;
+    const int col = n0 + wn * 64 + j * 16 + r16;
     const bool cok = col < p.Nout;
-    const float bias = cok ? p.bias[col] : 0.f;
-    const float iw = cok ? p.inv_w[col] : 0.f;
-    double cs = 0, cq = 0;
+    bias[j] = cok ? p.bias[col] : 0.f;
+    iw[j] = cok ? p.inv_w[col] : 0.f;
+  }
+  const int rrow = lane >> 4, rcol = (lane & 15) * 4;   // read-back: row rrow + 4q of the strip, columns rcol .. rcol + 3
+  const int gcol = n0 + wn * 64 + rcol;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < 8; ++i) {
+    const int64_t row0 = m0 + wm * 128 + i * 16;
+    float ia[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ia[r] = p.inv_a[row0 + 4 * ks + r < p.M ? row0 + 4 * ks + r : p.M - 1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool cok = n0 + wn * 64 + j * 16 + r16 < p.Nout;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int64_t row = m0 + wm * 128 + i * 16 + 4 * ks + r;
-        if (row < p.M && cok) {
-          const float y = fmaf(acc[i][j][r] * p.inv_a[row], iw, bias);
-          p.Y[row * p.ldy + col] = y;
+        const float y = fmaf(acc[i][j][r] * ia[r], iw[j], bias[j]);
+        stg[(4 * ks + r) * kStgLd + j * 16 + r16] = y;
+        if (row0 + 4 * ks + r < p.M && cok) {
           ymax = fmaxf(ymax, fabsf(y));
-          cs += y;
-          cq += (double)y * y;
+          cs[j] += y;
+          cq[j] += (double)y * y;
         }
       }
     }
-    cs += __shfl_xor(cs, 16, 64);
-    cq += __shfl_xor(cq, 16, 64);
-    cs += __shfl_xor(cs, 32, 64);
-    cq += __shfl_xor(cq, 32, 64);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // (LDS executes a wave's accesses in order: this only
+    __builtin_amdgcn_wave_barrier();                              //  keeps the compiler from reordering across lanes' data)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rr = rrow + 4 * q;
+      const int64_t row = row0 + rr;
+      const float4 v = *reinterpret_cast<const float4*>(stg + rr * kStgLd + rcol);
+      if (row < p.M) {
+        float* dst = p.Y + row * p.ldy + gcol;
+        if (vec_ok && gcol + 3 < p.Nout) {
+          *reinterpret_cast<float4*>(dst) = v;
+        } else {
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (gcol + t < p.Nout) dst[t] = vv[t];
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int cl = wn * 64 + j * 16 + r16;
+    double a = cs[j], b = cq[j];
+    a += __shfl_xor(a, 16, 64);
+    b += __shfl_xor(b, 16, 64);
+    a += __shfl_xor(a, 32, 64);
+    b += __shfl_xor(b, 32, 64);
     if (lane < 16) {
-      colred[(wm * 2 + 0) * BT + cl] = cs;
-      colred[(wm * 2 + 1) * BT + cl] = cq;
+      colred[(wm * 2 + 0) * BT + cl] = a;
+      colred[(wm * 2 + 1) * BT + cl] = b;
     }
   }
   __syncthreads();

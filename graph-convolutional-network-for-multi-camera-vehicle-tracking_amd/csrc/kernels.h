@@ -15,6 +15,7 @@ struct Knobs {
   bool gemm_fp32;            // MTMC_GEMM_FP32: exact-fp32 MFMA encoder everywhere
   bool gemm_no_f16;          // MTMC_GEMM_NO_F16: bf16x6 (large) / exact fp32 (few rows) instead of the fp16 split kernels
   bool gemm_no_presplit;     // MTMC_GEMM_NO_PRESPLIT: layer 0 of many-row graphs on the in-loop kernel
+  bool gemm_no_staged;       // MTMC_GEMM_NO_STAGED: layers >= 1 of many-row graphs on the in-loop kernel
 };
 const Knobs& knobs();
 
@@ -118,6 +119,21 @@ struct SplitGemmParams {
   unsigned* amax_y;                         // u32[kAmaxRep] (atomicMax) or nullptr
   int64_t M; int K; int Nout;
 };
+// Encoder layers >= 1 of many-row graphs (gemm_staged.hip): A = raw outputs of the previous layer (its BatchNorm + ReLU
+// applied by producer waves on the way into LDS), W = the layer's weights pre-split by launch_split_rows.
+struct StagedGemmParams {
+  const float* A; int64_t lda;              // [M][K] raw Y of the previous layer
+  const double* stats_in; const float* gamma_in; const float* beta_in; double count;   // its column statistics / BatchNorm
+  const unsigned* amax_a;                   // u32[kAmaxRep]: its |Y|max
+  const _Float16* Wh; const float* inv_w;   // [2][Nout][K] planes (k-tile-major, swizzled), [Nout] inverse row scales
+  const float* bias;
+  float* Y; int64_t ldy;
+  double* stats_out;                        // f64[2*Nout], accumulated atomically
+  unsigned* amax_y;                         // u32[kAmaxRep] (atomicMax) or nullptr
+  int64_t M; int K; int Nout;
+};
+bool staged_layer(int64_t rows, int K, int Nout);       // many rows, K % 32 == 0, K <= 2048, Nout % 128 == 0, not disabled
+int launch_gemm_staged(const StagedGemmParams& p, hipStream_t s);   // 0 ok, 1 unsupported shape, MTMC_E_HIP
 void launch_split_rows(const float* X, int64_t ld, int64_t rows, int K, void* H, float* inv, hipStream_t s);
 // hipFuncAttributeMaxDynamicSharedMemorySize, once per (kernel, device); false when HIP refuses (gemm_bn.hip)
 bool allow_big_lds(const void* fn, int bytes);

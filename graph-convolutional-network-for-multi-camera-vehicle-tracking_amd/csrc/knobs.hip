@@ -18,6 +18,7 @@ static Knobs read_knobs() {
   k.gemm_fp32 = on("MTMC_GEMM_FP32");
   k.gemm_no_f16 = on("MTMC_GEMM_NO_F16");
   k.gemm_no_presplit = on("MTMC_GEMM_NO_PRESPLIT");
+  k.gemm_no_staged = on("MTMC_GEMM_NO_STAGED");
   return k;
 }
 

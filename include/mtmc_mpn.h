@@ -197,11 +197,13 @@ int32_t mtmc_mpn_run_phase(const mtmc_mpn_model* model, const mtmc_mpn_call* cal
 /* Which kernels a call would run -- a host-only query (nothing is launched, no pointer of `call` is read: only its
  * sizes, ranges, flags and `training`), so that a multi-GPU host or a test can check that a SHARD takes the kernels the
  * whole graph would.  Encoder layers are planned for the node_hi - node_lo rows the call encodes. */
-enum { MTMC_GEMM_GENERIC = 0, MTMC_GEMM_INLOOP_64 = 1, MTMC_GEMM_INLOOP_128 = 2, MTMC_GEMM_PRESPLIT_256 = 3 };
+enum { MTMC_GEMM_GENERIC = 0, MTMC_GEMM_INLOOP_64 = 1, MTMC_GEMM_INLOOP_128 = 2, MTMC_GEMM_PRESPLIT_256 = 3,
+       MTMC_GEMM_STAGED_128 = 4 };
 enum { MTMC_PASS_C_WALK = 0, MTMC_PASS_C_MFMA_SORTED = 1, MTMC_PASS_C_MFMA_ANY = 2 };
 typedef struct mtmc_mpn_plan {
   int32_t enc_kernel[MTMC_MAX_ENC_LAYERS];   /* MTMC_GEMM_*: one-thread-per-output fallback / in-loop operand split on
-                                                64x64 or 128x128 tiles / pre-split fp16 planes + 256x256 tiles      */
+                                                64x64 or 128x128 tiles / pre-split fp16 planes + 256x256 tiles / (layers
+                                                >= 1 of many-row graphs) 128-row tiles staged by producer waves      */
   int32_t enc_split_k[MTMC_MAX_ENC_LAYERS];  /* K slices (few-row layers; > 1 => MTMC_PH_NODE_COMBINE does work)    */
   int32_t edges_per_thread;                  /* passes A / B                                                        */
   int32_t lazy_edges;                        /* 1: e' is never stored, consumers recompute it from z1               */

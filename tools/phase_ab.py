@@ -24,3 +24,5 @@ for (ph, arg), t in zip(seq, ms):
     k = bench.PHASE_NAMES[ph] + (f"[{arg}]" if ph == bench._lib.PH_NODE_ENC else "")
     tot[k] = tot.get(k, 0.0) + t
 print(f"{name}: forward {sec * 1e3:.3f} ms (median {dist['median']:.3f});", {k: round(v, 3) for k, v in tot.items()})
+if os.environ.get("DETAIL"):      # every launch by (phase, arg)
+    print("   per launch:", {f"{bench.PHASE_NAMES[ph].split('_kernel')[0]}[{arg}]": round(t, 4) for (ph, arg), t in zip(seq, ms) if t > 2e-3})
