@@ -57,7 +57,7 @@ class Plan(C.Structure):
                 ("avg_degree", C.c_double)]
 
 
-GEMM_GENERIC, GEMM_INLOOP_64, GEMM_INLOOP_128, GEMM_PRESPLIT_256 = range(4)
+GEMM_GENERIC, GEMM_INLOOP_64, GEMM_INLOOP_128, GEMM_PRESPLIT_256, GEMM_STAGED_128 = range(5)
 PASS_C_WALK, PASS_C_MFMA_SORTED, PASS_C_MFMA_ANY = range(3)
 
 # statistics blocks (include/mtmc_mpn.h): replicas x stride doubles each
@@ -72,7 +72,7 @@ EXPORTS = ["mtmc_mpn_abi_version", "mtmc_mpn_last_error", "mtmc_mpn_workspace_by
            "mtmc_build_graph", "mtmc_postprocess_workspace_bytes", "mtmc_postprocess",
            "mtmc_cross_entropy_forward", "mtmc_cross_entropy_backward",
            "mtmc_cross_entropy_steps_forward", "mtmc_cross_entropy_steps_backward", "mtmc_mpn_backward_steps", "mtmc_mpn_backward_flat", "mtmc_mpn_grad_layout", "mtmc_linear_raw", "mtmc_edge_confusion",
-           "mtmc_linear_presplit_raw"]
+           "mtmc_linear_presplit_raw", "mtmc_linear_staged_raw"]
 
 _lib = None
 
@@ -118,6 +118,10 @@ def load() -> C.CDLL:
     lib.mtmc_linear_presplit_raw.restype = C.c_int32
     lib.mtmc_linear_presplit_raw.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                              C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.mtmc_linear_staged_raw.restype = C.c_int32
+    lib.mtmc_linear_staged_raw.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mtmc_linear_raw.restype = C.c_int32
     lib.mtmc_linear_raw.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -159,6 +163,26 @@ def load() -> C.CDLL:
         raise RuntimeError("mtmc_mpn: ABI version mismatch between _lib.py and libmtmc_mpn.so")
     _lib = lib
     return lib
+
+
+LAB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmtmc_lab.so")
+_lab = None
+
+
+def load_lab() -> C.CDLL:
+    """The kernel laboratory (csrc/lab/, libmtmc_lab.so): A/B variants and timing experiments of the pre-split GEMM for
+    tools/presplit_time.py and tests/test_gpu_gemm_presplit.py.  Test / tool infrastructure -- the package never loads it."""
+    global _lab
+    if _lab is None:
+        load()
+        if not os.path.exists(LAB_PATH):
+            raise RuntimeError(f"mtmc_mpn: {LAB_PATH} missing; run `python -m mtmc_mpn.build`")
+        _lab = C.CDLL(LAB_PATH)
+        _lab.mtmc_lab_linear_presplit_raw.restype = C.c_int32
+        _lab.mtmc_lab_linear_presplit_raw.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                                      C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                                      C.c_int32, C.c_void_p]
+    return _lab
 
 
 def check(rc: int):

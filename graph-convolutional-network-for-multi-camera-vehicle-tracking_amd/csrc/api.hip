@@ -210,9 +210,40 @@ int32_t mtmc_linear_raw(const float* A, int64_t lda, const float* W, const float
   return e == hipSuccess ? MTMC_OK : fail(MTMC_E_HIP, "launch failed: %s", hipGetErrorString(e));
 }
 
+// Diagnostics / unit tests: one encoder layer >= 1 as the forward runs it on many-row graphs (gemm_staged.hip):
+// Y[M][N] = relu(bn(A))[M][K] . W[N][K]^T + bias, bn = BatchNorm with the given column statistics (f64 sum[K] | sumsq[K] over
+// `count` rows) and gamma / beta.  work: >= 4*N*K + 4*N + 256 bytes (the weight planes); scratch: u32[48]; stats: f64[2*N] or NULL.
+int32_t mtmc_linear_staged_raw(const float* A, int64_t lda, const double* stats_in, const float* gamma_in, const float* beta_in,
+                               double count, const float* W, const float* bias, float* Y, int64_t M, int32_t K, int32_t N,
+                               void* work, uint64_t work_bytes, uint32_t* scratch, double* stats, void* stream) {
+  if (!A || !stats_in || !gamma_in || !beta_in || !W || !bias || !Y || !work || !scratch || M < 1 || K < 64 || K % 32 || K > 2048 ||
+      N < 256 || N % 256 || lda < K || (lda & 3) || ((uintptr_t)A & 15))
+    return fail(MTMC_E_ARG, "bad arguments");
+  const uint64_t iw_off = ((uint64_t)N * K * 4 + 255) / 256 * 256;
+  if (work_bytes < iw_off + (uint64_t)N * 4) return fail(MTMC_E_ARG, "work buffer too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(scratch, 0, 3 * mtmc::kAmaxRep * sizeof(uint32_t), s) != hipSuccess) return fail(MTMC_E_HIP, "hipMemsetAsync failed");
+  if (stats && hipMemsetAsync(stats, 0, 2 * (size_t)N * sizeof(double), s) != hipSuccess) return fail(MTMC_E_HIP, "hipMemsetAsync failed");
+  mtmc::PrepParams pp = {};
+  pp.n_edges = 0; pp.n_jobs = 1;
+  pp.jobs[0] = {A, M, K, lda, scratch, 0, 0};
+  mtmc::launch_prep(pp, s);
+  unsigned char* wk = static_cast<unsigned char*>(work);
+  mtmc::launch_split_rows(W, K, N, K, wk, reinterpret_cast<float*>(wk + iw_off), s);
+  mtmc::StagedGemmParams g;
+  g.A = A; g.lda = lda; g.stats_in = stats_in; g.gamma_in = gamma_in; g.beta_in = beta_in; g.count = count;
+  g.amax_a = scratch; g.Wh = reinterpret_cast<const _Float16*>(wk); g.inv_w = reinterpret_cast<const float*>(wk + iw_off);
+  g.bias = bias; g.Y = Y; g.ldy = N; g.stats_out = stats; g.amax_y = scratch + 2 * mtmc::kAmaxRep;
+  g.M = M; g.K = K; g.Nout = N;
+  const int rc = mtmc::launch_gemm_staged(g, s);
+  if (rc != 0) return fail(rc == MTMC_E_HIP ? MTMC_E_HIP : MTMC_E_ARG, "unsupported shape or launch refused");
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MTMC_OK : fail(MTMC_E_HIP, "launch failed: %s", hipGetErrorString(e));
+}
+
 int32_t mtmc_linear_presplit_raw(const float* A, int64_t lda, const float* W, const float* bias, float* Y, int64_t M,
                                  int32_t K, int32_t N, void* work, uint64_t work_bytes, uint32_t* scratch, double* stats,
-                                 int32_t variant, void* stream) {
+                                 int32_t reuse_planes, void* stream) {
   if (!A || !W || !bias || !Y || !work || !scratch || M < 1 || K < 64 || K % 64 || K > 2048 || N < 1)
     return fail(MTMC_E_ARG, "bad arguments");
   const uint64_t a_bytes = (uint64_t)M * K * 4, w_bytes = (uint64_t)N * K * 4;
@@ -222,18 +253,17 @@ int32_t mtmc_linear_presplit_raw(const float* A, int64_t lda, const float* W, co
   if (hipMemsetAsync(scratch, 0, 3 * mtmc::kAmaxRep * sizeof(uint32_t), s) != hipSuccess) return fail(MTMC_E_HIP, "hipMemsetAsync failed");
   if (stats && hipMemsetAsync(stats, 0, 2 * (size_t)N * sizeof(double), s) != hipSuccess) return fail(MTMC_E_HIP, "hipMemsetAsync failed");
   unsigned char* wk = static_cast<unsigned char*>(work);
-  if (variant >= 0) {
+  if (!reuse_planes) {
     mtmc::launch_split_rows(A, lda, M, K, wk, reinterpret_cast<float*>(wk + ia_off), s);
     mtmc::launch_split_rows(W, K, N, K, wk + wh_off, reinterpret_cast<float*>(wk + iw_off), s);
-  } else {
-    variant = -variant - 1;          // negative: the planes in `work` are reused (times the GEMM alone)
   }
   mtmc::SplitGemmParams g;
   g.Ah = reinterpret_cast<const _Float16*>(wk); g.inv_a = reinterpret_cast<const float*>(wk + ia_off);
   g.Wh = reinterpret_cast<const _Float16*>(wk + wh_off); g.inv_w = reinterpret_cast<const float*>(wk + iw_off);
   g.bias = bias; g.Y = Y; g.ldy = N; g.stats_out = stats; g.amax_y = scratch + 2 * mtmc::kAmaxRep;
   g.M = M; g.K = K; g.Nout = N;
-  if (mtmc::launch_gemm_presplit(g, s, variant) != 0) return fail(MTMC_E_ARG, "unsupported shape");
+  const int rc = mtmc::launch_gemm_presplit(g, s);
+  if (rc != 0) return fail(rc == MTMC_E_HIP ? MTMC_E_HIP : MTMC_E_ARG, "unsupported shape or launch refused");
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? MTMC_OK : fail(MTMC_E_HIP, "launch failed: %s", hipGetErrorString(e));
 }

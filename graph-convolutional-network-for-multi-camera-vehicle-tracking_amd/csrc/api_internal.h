@@ -386,9 +386,7 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
         q.stats_out = x.at<double>(x.lo.stat_enc_layer[0]);
         q.amax_y = x.at<unsigned>(x.lo.amax) + (1 + MTMC_MAX_ENC_LAYERS) * mtmc::kAmaxRep;
         q.M = rows; q.K = Lr.in_dim; q.Nout = Lr.out_dim;
-        // the 16x16x32-MFMA kernel: 1.09 ms against 1.14 (mid-barrier, 32x32x16) / 1.15 ms (plain loop, 32x32x16) at
-        // 100000 x 2048 x 1024 on one box -- fewer joules per flop at the power cap this GEMM runs at
-        const int rc = mtmc::launch_gemm_presplit(q, s, 11);
+        const int rc = mtmc::launch_gemm_presplit(q, s);
         if (rc != 0) return fail(rc == MTMC_E_HIP ? MTMC_E_HIP : MTMC_E_ARG, "encoder layer 0: pre-split GEMM refused the shape or the launch");
         break;
       }

@@ -688,8 +688,12 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
       {
         const float* pa = p.Q + (int64_t)qa_row * kH + k;
         const float* pb = p.Q + (int64_t)qb_row * kH + k;
-        asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off"
-                     : "=&v"(qa), "=&v"(qb) : "v"(pa), "v"(pb) : "memory");
+        // (the s_mov with the 0xc0de0001 literal marks the pair for tools/check_isa.py, rule COUNTED-WAIT: at build time the
+        // lint verifies on the code object that exactly two vector loads, no store and no touch of %0 / %1 sit between
+        // here and the marked wait below -- the things this sequence relies on and the compiler knows nothing about)
+        int mark;
+        asm volatile("s_mov_b32 %2, 0xc0de0001\n\tglobal_load_dword %0, %3, off\n\tglobal_load_dword %1, %4, off"
+                     : "=&v"(qa), "=&v"(qb), "=s"(mark) : "v"(pa), "v"(pb) : "memory");
       }
       fetch(chunk + 1);
       float lg0 = 0.f, lg1 = 0.f;
@@ -731,7 +735,10 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
         }
       }
       // Q lookups done (the two prefetch loads may still be in flight); stores only from here on -- they share the counter
-      asm volatile("s_waitcnt vmcnt(2)" : "+v"(qa), "+v"(qb) : : "memory");
+      {
+        int mark;
+        asm volatile("s_mov_b32 %2, 0xc0de0002\n\ts_waitcnt vmcnt(2)" : "+v"(qa), "+v"(qb), "=s"(mark) : : "memory");
+      }
       if (want_logits && valid) {                                // ... the store after the counted wait
         if (p.n_classes == 2) {
           reinterpret_cast<float2*>(p.logits)[e] = make_float2(lg0, lg1);

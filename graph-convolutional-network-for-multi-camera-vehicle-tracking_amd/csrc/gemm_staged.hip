@@ -3,58 +3,58 @@
 //
 // gemm_bn_f16x3_kernel (gemm_bn.hip) does everything in every wave: global load -> BatchNorm affine + ReLU -> two-piece fp16
 // split -> ds_write -> barrier -> ds_read -> MFMA.  Conversion and staging alternate with the matrix work instead of
-// overlapping it: layer 1 of config 4 (100000 x 1024 -> 512) ran at 0.26 of its bound.  Here a 512-thread workgroup is
-// split by ROLE (the SIMDs each host one wave of either kind: MI355X_MICROARCH.md, wave placement 0->2->1->3):
+// overlapping it: layer 1 of config 4 (100000 x 1024 -> 512) ran at 0.26 of its bound.  Here a 768-thread workgroup is
+// split by ROLE; the waves of a workgroup go to the SIMDs cyclically (MI355X_MICROARCH.md), so every SIMD hosts one
+// producer and two consumers:
 //   waves 0-3  PRODUCERS  A: global load (fp32 raw Y_prev, one k-tile ahead in registers) -> affine + ReLU -> scale ->
-//                            fp16 pieces (v_cvt_pkrtz) -> ds_write_b128 into the NEXT stage, in the swizzled image the
+//                            fp16 pieces (v_cvt_pkrtz) -> ds_write_b64 into the NEXT stage, in the swizzled image the
 //                            fragment reads want;
-//                         W: LDS-DMA of the layer's PRE-SPLIT weight planes (split_rows_kernel, once per forward: the same
-//                            [rows][32] k-tile-major swizzled image as layer 0's operands) two k-tiles ahead;
-//   waves 4-7  CONSUMERS  ds_read_b128 fragments + v_mfma_f32_32x32x16_f16, three products per fp32 product (a1w0 + a0w1 + a0w0);
+//   waves 4-11 CONSUMERS  W: LDS-DMA of the layer's PRE-SPLIT weight planes (split_rows_kernel, once per forward: the same
+//                            [rows][32] k-tile-major swizzled image as layer 0's operands) two k-tiles ahead, three stages;
+//                         ds_read_b128 fragments + v_mfma_f32_16x16x32_f16, three products per fp32 product;
 // one s_barrier per k-tile.  The VALU work of a producer runs in the issue slots the consumer's MFMAs leave free
 // (an MFMA holds the SIMD's vector issue for 8 of its 32 cycles), the weight bytes never touch a VGPR, and an A element is
 // converted Nout / BN times instead of Nout / 128.
-// Tile: 128 rows x BN columns (BN = 256: layer 1; 128: layer 2), BK = 32; consumers 2 x 2, 64 x BN/2 each.
+// Tile: up to 128 rows x BN = 256 columns, BK = 32 (A two stages, W three); consumers 2 x 4, 64 x BN/4 each.
 // Accuracy: the same two-piece split as the other encoder kernels (22 mantissa bits per operand);
 // A scale: one power of two per launch from |Y_prev|max and the BatchNorm affine (as gemm_bn_f16x3_kernel), W: one per row.
 #include <hip/hip_runtime.h>
 
 #include "common.h"
 #include "kernels.h"
+#include "lds_dma.h"
 
 namespace mtmc {
 
-typedef _Float16 f16x8s __attribute__((ext_vector_type(8)));
-typedef float f32x16s __attribute__((ext_vector_type(16)));
-typedef __fp16 h2s_t __attribute__((ext_vector_type(2)));
 
 constexpr int kSgBM = 128, kSgBK = 32, kSgRowB = kSgBK * 2;      // bytes per image row
 constexpr int kSgAImg = kSgBM * kSgRowB;                         // one A piece of one stage: 8 KB
-constexpr int kSgNA = 2, kSgNW = 3;                              // stages: A double-buffered, W three deep
-
-// (as gemm_presplit.hip: the LDS-DMA form that costs the issuing wave no VALU instruction; the compiler does not count
-// it in vmcnt, every wait on it is written out)
-__device__ __forceinline__ void sg_lds_dma16(const void* base, unsigned lane_off, unsigned lds) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(base), "s"(lds) : "memory");
-}
+constexpr int kSgNT = 768;                                       // 4 producer + 8 consumer waves: one + two per SIMD
+constexpr int kSgSets = 3;                                       // register sets of the producers: A is loaded two k-tiles ahead
+constexpr int kSgNW = 3;                                         // W stages: LDS-DMA runs two k-tiles ahead (a DMA takes
+                                                                 // ~1 us from issue to landed under load, a k-tile less)
 
 template <int BN>
-__global__ __launch_bounds__(512, 1) void gemm_staged_kernel(StagedGemmParams p, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(kSgNT) void gemm_staged_kernel(StagedGemmParams p, int tiles_m, int tiles_n, int bm) {
   constexpr int WIMG = BN * kSgRowB;                   // one W piece of one stage
-  constexpr int TJ = BN / 64;                          // 32-column blocks per consumer wave (its share: 64 rows x BN/2 columns)
-  constexpr int WJ = BN / 64;                          // DMA instructions per W piece per producer wave pass (64 rows each)
+  constexpr int WC = BN / 4;                           // columns per consumer wave (2 x 4 waves, 64 rows x WC columns each)
+  constexpr int TJ = WC / 16;                          // 16-column blocks per consumer wave: 4 or 2
+  constexpr int WJ = BN / 128;                         // DMA instructions per W piece per consumer wave (128 rows per pass of the eight)
+  constexpr int WST = 2 * WIMG, AST = 2 * kSgAImg;     // one stage of W (piece 1, piece 2) / of A
+  constexpr int A0 = kSgNW * WST;                      // LDS: [kSgNW] W stages, then [2] A stages, then the input affine
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* w_st = smem;                                        // [kSgNW][2][BN][64 B]
-  unsigned char* a_st = smem + kSgNW * 2 * WIMG;                     // [kSgNA][2][128][64 B]
-  float* s_in = reinterpret_cast<float*>(a_st + kSgNA * 2 * kSgAImg);   // [K]
+  float* s_in = reinterpret_cast<float*>(smem + A0 + 2 * AST);       // [K]
   float* t_in = s_in + p.K;                                          // [K]
   float* sc = t_in + p.K;                                            // [4]: scale of A, -, 1 / scale of A, -
-  float* wred = sc + 4;                                              // [16]
+  float* wred = sc + 4;                                              // [24]
 
+  // (the integer division runs on the vector unit: pin the uniform results to scalar registers, so that everything
+  // derived from the tile origin -- the LDS-DMA base addresses above all -- stays on the scalar unit)
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int tm_idx = (slot / tiles_n) * 8 + xcd, tn_idx = slot % tiles_n;
+  const int tm_idx = __builtin_amdgcn_readfirstlane((slot / tiles_n) * 8 + xcd);
+  const int tn_idx = __builtin_amdgcn_readfirstlane(slot % tiles_n);
   if (tm_idx >= tiles_m) return;
-  const int64_t m0 = (int64_t)tm_idx * kSgBM;
+  const int64_t m0 = (int64_t)tm_idx * bm;             // bm: the tile's height, a multiple of 16 in [80, 128] (launch_gemm_staged)
   const int n0 = tn_idx * BN;
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool producer = wid < 4;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(512, 1) void gemm_staged_kernel(StagedGemmParams p,
   // ---- prologue (everyone): BatchNorm affine of the K input columns, the bound on |relu(bn(.))| -> the A scale
   {
     float ms = 0.f, mt = 0.f;
-    for (int kk = threadIdx.x; kk < p.K; kk += 512) {
+    for (int kk = threadIdx.x; kk < p.K; kk += kSgNT) {
       float sv, tv;
       bn_affine(p.stats_in[kk], p.stats_in[p.K + kk], p.count, p.gamma_in[kk], p.beta_in[kk], sv, tv);
       s_in[kk] = sv; t_in[kk] = tv;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(512, 1) void gemm_staged_kernel(StagedGemmParams p,
       ms = fmaxf(ms, __shfl_xor(ms, off, 64));
       mt = fmaxf(mt, __shfl_xor(mt, off, 64));
     }
-    if (lane == 0) { wred[wid] = ms; wred[8 + wid] = mt; }
+    if (lane == 0) { wred[wid] = ms; wred[12 + wid] = mt; }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(512, 1) void gemm_staged_kernel(StagedGemmParams p,
     for (int r = 0; r < kAmaxRep; ++r) ua = max(ua, p.amax_a[r]);
     float s8 = 0.f, t8 = 0.f;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) { s8 = fmaxf(s8, wred[w]); t8 = fmaxf(t8, wred[8 + w]); }
+    for (int w = 0; w < 12; ++w) { s8 = fmaxf(s8, wred[w]); t8 = fmaxf(t8, wred[12 + w]); }
     const float bound = fmaf(__uint_as_float(ua), s8, t8);
     int ea = 0;
     if (bound > 0.f && bound < 3e38f) (void)frexpf(bound, &ea);
@@ -94,190 +94,241 @@ __global__ __launch_bounds__(512, 1) void gemm_staged_kernel(StagedGemmParams p,
   __syncthreads();
   const float sa = sc[0];
   const int nk = p.K / kSgBK;
-  const unsigned lds0 = (unsigned)(size_t)smem;
+
+  f32x4v acc[4][TJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
   if (producer) {
-    // ---- A: lane t takes 16-byte slot (t & 3) (k = 8 * slot .. + 7 of the k-tile) of rows (t >> 2) and (t >> 2) + 64
-    const int pt = threadIdx.x, sp = pt & 3, r0 = pt >> 2;
-    const float* a_src[2];
-    unsigned a_dst[2];
+    // ==== PRODUCERS (waves 0-3): the A operand.  These waves issue NO LDS-DMA: every vector-memory operation of theirs is a
+    // plain load the compiler counts, so its own s_waitcnt vmcnt(N) in front of the conversion is exact and leaves the
+    // younger k-tiles' loads in flight.  (Mixed with hand-counted LDS-DMA in one wave the compiler's count is short by the
+    // DMA instructions and its wait drains them too: the first version of this kernel paid a DMA latency per k-tile.)
+    // Lane t takes the 16-byte chunk (t & 7) -- k = 4 * chunk .. + 3 of the k-tile -- of rows (t >> 3) + 32 h, h = 0..3:
+    // a load instruction reads whole 128-byte lines, eight rows per wave.
+    const int pt = threadIdx.x, c8 = pt & 7, r0 = pt >> 3;
+    const float* a_src[4];
+    unsigned a_dst[4];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int r = r0 + 64 * h;
-      const int64_t row = m0 + r < p.M ? m0 + r : p.M - 1;           // rows past M: any valid row (never stored)
-      a_src[h] = p.A + row * p.lda + sp * 8;
-      a_dst[h] = (unsigned)(r * kSgRowB + ((sp ^ ((r >> 2) & 3)) << 4));
+    for (int h = 0; h < 4; ++h) {
+      const int r = r0 + 32 * h;
+      const int64_t row = (r < bm && m0 + r < p.M) ? m0 + r : m0;    // rows past M or past the tile's height: the tile's
+      a_src[h] = p.A + row * p.lda + c8 * 4;                         // first row again (cached; what they feed is never stored)
+      a_dst[h] = (unsigned)(r * kSgRowB + (((c8 >> 1) ^ ((r >> 2) & 3)) << 4) + (c8 & 1) * 8);   // the fragment reads' swizzle
     }
-    // ---- W: thread t fills chunk (t & 3) of rows (t >> 2) + 64 j of both pieces: uniform base + loop-invariant lane offset
+    float4 ra[kSgSets][4];                               // [register set][row]
+    auto load_a = [&](int kt, int set) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) ra[set][h] = *reinterpret_cast<const float4*>(a_src[h] + kt * kSgBK);
+    };
+    auto convert_a = [&](int kt, int set) {
+      unsigned char* st = smem + A0 + (kt & 1) * AST;
+      const float4 s4 = *reinterpret_cast<const float4*>(s_in + kt * kSgBK + c8 * 4);
+      const float4 t4 = *reinterpret_cast<const float4*>(t_in + kt * kSgBK + c8 * 4);
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const float4 v = ra[set][h];
+        // relu(bn(y)) scaled into fp16's range, then h1 = rtz(x), h2 = rtz(x - h1) (exact residual; see gemm_bn.hip `put`)
+        const float x0 = fmaxf(fmaf(v.x, s4.x, t4.x), 0.f) * sa, x1 = fmaxf(fmaf(v.y, s4.y, t4.y), 0.f) * sa;
+        const float x2 = fmaxf(fmaf(v.z, s4.z, t4.z), 0.f) * sa, x3 = fmaxf(fmaf(v.w, s4.w, t4.w), 0.f) * sa;
+        const h2_t a01 = __builtin_amdgcn_cvt_pkrtz(x0, x1), a23 = __builtin_amdgcn_cvt_pkrtz(x2, x3);
+        const h2_t b01 = __builtin_amdgcn_cvt_pkrtz(x0 - (float)a01[0], x1 - (float)a01[1]);
+        const h2_t b23 = __builtin_amdgcn_cvt_pkrtz(x2 - (float)a23[0], x3 - (float)a23[1]);
+        uint2 q1, q2;
+        q1.x = __builtin_bit_cast(unsigned, a01); q1.y = __builtin_bit_cast(unsigned, a23);
+        q2.x = __builtin_bit_cast(unsigned, b01); q2.y = __builtin_bit_cast(unsigned, b23);
+        *reinterpret_cast<uint2*>(st + a_dst[h]) = q1;
+        *reinterpret_cast<uint2*>(st + kSgAImg + a_dst[h]) = q2;
+      }
+    };
+    // One k-tile of producer work.  A(k) lives in register set k % 3: tile kt+3 is loaded into set `ld` = kt % 3 (free:
+    // A(kt) went to LDS one k-tile ago) while tile kt+1, loaded TWO k-tiles ago, is converted out of set `cv` = (kt+1) % 3.
+    // ld / cv are literals at the call sites, so the register arrays are indexed statically after inlining.
+    auto step = [&](int kt, int ld, int cv) {
+      if (kt + 3 < nk) load_a(kt + 3, ld);
+      if (kt + 1 < nk) convert_a(kt + 1, cv);            // -> A stage (kt+1)&1: the consumers left it at the last barrier
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    };
+    load_a(0, 0);
+    if (nk > 1) load_a(1, 1);
+    if (nk > 2) load_a(2, 2);
+    convert_a(0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // pipeline filled (the consumers' W(0) has landed too)
+    for (int kt = 0; kt < nk; kt += 3) {
+      step(kt, 0, 1);
+      if (kt + 1 < nk) step(kt + 1, 1, 2);
+      if (kt + 2 < nk) step(kt + 2, 2, 0);
+    }
+  } else {
+    // ==== CONSUMERS (waves 4-11, two per SIMD beside one producer): 2 x 4 waves, 64 rows x WC columns each, as 4 x TJ
+    // blocks of v_mfma_f32_16x16x32_f16 (the layer-0 kernel's fragment reads, gemm_presplit.hip).  They also bring in the
+    // W operand -- LDS-DMA of the pre-split weight planes, one k-tile ahead, their only vector-memory traffic, so the
+    // waits below are exact; while one wave of a SIMD issues its DMA or waits for fragments, its partner's MFMAs keep the
+    // matrix pipe busy.  Thread t fills chunk (t & 3) of rows (t >> 2) + 128 j of both pieces: a uniform base (SGPRs,
+    // advanced by SALU) + a loop-invariant lane offset.
+    const int cw = wid - 4, ct = threadIdx.x - 256;
+    const int wm = cw >> 2, wn = cw & 3;
     unsigned off_w[WJ];
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
-      const int r = r0 + 64 * j;
+      const int r = (ct >> 2) + 128 * j;
       const int br = n0 + r < p.Nout ? r : p.Nout - 1 - n0;
-      off_w[j] = (unsigned)(br * kSgBK + sp * 8) * 2u;
+      off_w[j] = (unsigned)(br * kSgBK + (ct & 3) * 8) * 2u;
     }
+    const unsigned lds0 = (unsigned)(size_t)smem;
     const char* w_tile = reinterpret_cast<const char*>(p.Wh + (int64_t)n0 * kSgBK);
     const int64_t w_plane = (int64_t)p.Nout * p.K * 2, w_kt = (int64_t)p.Nout * kSgBK * 2;
+    // one of the wave's 2 * WJ LDS-DMA instructions of k-tile kt (g = piece * WJ + pass)
+    auto dma_one = [&](int kt, int g) {
+      const int q = g / WJ, j = g % WJ;
+      lds_dma16(w_tile + q * w_plane + kt * w_kt, off_w[j], lds0 + (kt % kSgNW) * WST + cw * 1024 + q * WIMG + j * 8192);
+    };
     auto dma_w = [&](int kt) {
-      const unsigned st = lds0 + (kt % kSgNW) * 2 * WIMG + wid * 1024;
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const char* sb = w_tile + q * w_plane + kt * w_kt;
-#pragma unroll
-        for (int j = 0; j < WJ; ++j) sg_lds_dma16(sb, off_w[j], st + q * WIMG + j * 4096);
-      }
+      for (int g = 0; g < 2 * WJ; ++g) dma_one(kt, g);
     };
-    float4 ra[2][2][2];                                  // [register set][row half][float4 of the 8]
-    auto load_a = [&](int kt, int set) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        ra[set][h][0] = *reinterpret_cast<const float4*>(a_src[h] + kt * kSgBK);
-        ra[set][h][1] = *reinterpret_cast<const float4*>(a_src[h] + kt * kSgBK + 4);
-      }
-    };
-    auto convert_a = [&](int kt, int set) {
-      unsigned char* st = a_st + (kt & 1) * 2 * kSgAImg;
-      const float4 s0 = *reinterpret_cast<const float4*>(s_in + kt * kSgBK + sp * 8);
-      const float4 s1 = *reinterpret_cast<const float4*>(s_in + kt * kSgBK + sp * 8 + 4);
-      const float4 t0 = *reinterpret_cast<const float4*>(t_in + kt * kSgBK + sp * 8);
-      const float4 t1 = *reinterpret_cast<const float4*>(t_in + kt * kSgBK + sp * 8 + 4);
-      const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-      const float tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const float4 v0 = ra[set][h][0], v1 = ra[set][h][1];
-        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        uint4 q1, q2;
-        unsigned* o1 = reinterpret_cast<unsigned*>(&q1);
-        unsigned* o2 = reinterpret_cast<unsigned*>(&q2);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          // relu(bn(y)) scaled into fp16's range, then h1 = rtz(x), h2 = rtz(x - h1) (exact residual; see gemm_bn.hip `put`)
-          const float xa = fmaxf(fmaf(x[2 * e], sv[2 * e], tv[2 * e]), 0.f) * sa;
-          const float xb = fmaxf(fmaf(x[2 * e + 1], sv[2 * e + 1], tv[2 * e + 1]), 0.f) * sa;
-          const h2s_t hi = __builtin_amdgcn_cvt_pkrtz(xa, xb);
-          const h2s_t lo = __builtin_amdgcn_cvt_pkrtz(xa - (float)hi[0], xb - (float)hi[1]);
-          o1[e] = __builtin_bit_cast(unsigned, hi);
-          o2[e] = __builtin_bit_cast(unsigned, lo);
-        }
-        *reinterpret_cast<uint4*>(st + a_dst[h]) = q1;
-        *reinterpret_cast<uint4*>(st + kSgAImg + a_dst[h]) = q2;
-      }
-    };
+    const int r16 = lane & 15, ks = lane >> 4;                       // fragment row inside a 16-row block, 8-half k group
+    const int so = (ks ^ ((r16 >> 2) & 3)) * 16;                     // the stored swizzle: slot ^ ((row >> 2) & 3)
+    const int a_row = (wm * 64 + r16) * kSgRowB + so, b_row = (wn * WC + r16) * kSgRowB + so;
+    const int nblk = wm == 0 ? 4 : (bm - 64) / 16;                   // 16-row blocks of this wave (tile height bm: 80..128)
 
-    // One k-tile of producer work.  A(k) lives in register set k & 1: tile kt+2 is loaded into set `ld` = kt & 1 (free:
-    // A(kt) went to LDS one k-tile ago) while tile kt+1, loaded a whole k-tile ago, is converted out of set `cv`.
-    // ld / cv are literals at the call sites, so the register arrays are indexed statically after inlining.
-    auto step = [&](int kt, int ld, int cv) {
-      const bool more2 = kt + 2 < nk;
-      if (more2) load_a(kt + 2, ld);
-      if (kt + 1 < nk) convert_a(kt + 1, cv);            // -> A stage (kt+1)&1: the consumers left it at the last barrier
-      if (more2) {
-        dma_w(kt + 2);                                   // -> W stage (kt+2)%3 = (kt-1)%3: free since the last barrier
-        // W(kt+1) must have landed before the barrier: younger than it are this k-tile's 4 loads and 2*WJ DMA instructions
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 + 2 * WJ) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();
-    };
-    // pipeline fill: W(0), W(1) by DMA; A(0) converted into stage 0; A(1) in registers
     dma_w(0);
-    if (nk > 1) dma_w(1);
-    load_a(0, 0);
-    if (nk > 1) load_a(1, 1);
-    convert_a(0, 0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (int kt = 0; kt < nk; kt += 2) {
-      step(kt, 0, 1);
-      if (kt + 1 < nk) step(kt + 1, 1, 0);
+    if (nk > 1) {
+      dma_w(1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WJ) : "memory");  // W(0) landed, W(1) may fly
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-  }
-
-  // ---- consumers: 2 x 2 waves, 64 rows x BN/2 columns each
-  const int cw = wid & 3, wm = cw >> 1, wn = cw & 1;
-  const int fr = lane & 31, hi = lane >> 5;
-  f32x16s acc[2][TJ];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < TJ; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  if (!producer) {
-    const int gl = (fr >> 2) & 3;
-    const int a_row = (wm * 64 + fr) * kSgRowB, b_row = (wn * (BN / 2) + fr) * kSgRowB;
-    const int sx = (hi ^ gl) * 16;
     __builtin_amdgcn_s_barrier();                        // pairs with the producers' pipeline-fill barrier
     for (int kt = 0; kt < nk; ++kt) {
-      const unsigned char* as = a_st + (kt & 1) * 2 * kSgAImg;
-      const unsigned char* ws = w_st + (kt % kSgNW) * 2 * WIMG;
+      const bool more = kt + 2 < nk;                     // W(kt+2) -> W stage (kt+2)%3 = (kt-1)%3: everyone left it at the last barrier
+      const unsigned char* st = smem + (kt % kSgNW) * WST;
+      const unsigned char* as = smem + A0 + (kt & 1) * AST;
+      f16x8 b[TJ][2];
 #pragma unroll
-      for (int ks = 0; ks < kSgBK / 16; ++ks) {
-        const int so = sx ^ (ks * 32);
-        f16x8s a[2][2], b[TJ][2];
+      for (int j = 0; j < TJ; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int q = 0; q < 2; ++q) b[j][q] = *reinterpret_cast<const f16x8*>(st + q * WIMG + b_row + j * 16 * kSgRowB);
 #pragma unroll
-          for (int q = 0; q < 2; ++q) a[i][q] = *reinterpret_cast<const f16x8s*>(as + q * kSgAImg + a_row + i * 32 * kSgRowB + so);
+      for (int i = 0; i < 4; ++i) {
+        f16x8 a[2];
 #pragma unroll
-        for (int j = 0; j < TJ; ++j)
+        for (int q = 0; q < 2; ++q) a[q] = *reinterpret_cast<const f16x8*>(as + q * kSgAImg + a_row + i * 16 * kSgRowB);
+        if (i < nblk) {                                    // (rows past the tile's height: wave-uniform skip)
 #pragma unroll
-          for (int q = 0; q < 2; ++q) b[j][q] = *reinterpret_cast<const f16x8s*>(ws + q * WIMG + b_row + j * 32 * kSgRowB + so);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < TJ; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TJ; ++j) {                   // the three products of a block back to back (gemm_presplit.hip)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], b[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[j][1], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
           }
+        }
+        // the next k-tile's LDS-DMA goes out BETWEEN the blocks, behind MFMAs that are already queued: issued in one run
+        // right after the barrier, by all eight waves at once, it kept the matrix pipes idle for the CU's whole address queue
+        if (more) {
+#pragma unroll
+          for (int g = i * (2 * WJ) / 4; g < (i + 1) * (2 * WJ) / 4; ++g) dma_one(kt + 2, g);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragment reads are done: the stage may be refilled
+      // this wave's fragment reads are done (the stages may be refilled), and its share of W(kt+1) has landed -- W(kt+2),
+      // issued during this k-tile, stays in flight across the barrier
+      if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * WJ) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
   }
 
-  // ---- epilogue (consumers; the producers only join the barriers): undo the scales, bias, raw Y -- a 32 x 32 accumulator
-  // register is two whole 128-byte row segments per wave-instruction --, fp64 column statistics, |Y|max
+  // ---- epilogue (consumers; the producers only join the barriers): undo the scales, bias, raw Y through a per-wave LDS
+  // transposition (whole row segments of 4 * WC bytes, as gemm_f16p_m16_kernel), fp64 column statistics, |Y|max
   __syncthreads();
-  double* colred = reinterpret_cast<double*>(smem);     // [2 (wm)][2 (sum, sq)][BN]
+  const int cw = (wid + 4) & 7, wm = cw >> 2, wn = cw & 3;            // (wid - 4 for the consumers)
+  float* stg = reinterpret_cast<float*>(smem) + cw * (16 * WC);
+  double* colred = reinterpret_cast<double*>(smem + 8 * 16 * WC * sizeof(float));   // [2 (wm)][2 (sum, sq)][BN], behind the strips
   float ymax = 0.f;
   if (!producer) {
+    const int r16 = lane & 15, ks = lane >> 4;
     const float inv_a = sc[2];
+    const bool vec_ok = (p.ldy & 3) == 0 && ((uintptr_t)p.Y & 15) == 0;
+    float bias[TJ], iw[TJ];
+    double cs[TJ], cq[TJ];
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
-      const int cl = wn * (BN / 2) + j * 32 + fr;
-      const int col = n0 + cl;
+      const int col = n0 + wn * WC + j * 16 + r16;
       const bool cok = col < p.Nout;
-      const float bias = cok ? p.bias[col] : 0.f;
-      const float iw = cok ? p.inv_w[col] : 0.f;
-      double cs = 0, cq = 0;
+      bias[j] = cok ? p.bias[col] : 0.f;
+      iw[j] = cok ? p.inv_w[col] : 0.f;
+      cs[j] = cq[j] = 0;
+    }
+    constexpr int LPR = WC / 4;                          // lanes per staged row on the way out (16 bytes each): 16 or 8
+    constexpr int RPI = 64 / LPR;                        // rows per store instruction: 4 or 8
+    const int rrow = lane / LPR, rcol = (lane % LPR) * 4;
+    const int gcol = n0 + wn * WC + rcol;
+    const int nblk = wm == 0 ? 4 : (bm - 64) / 16;
+    const int64_t m_end = m0 + bm < p.M ? m0 + bm : p.M;             // rows of this tile: [m0, m_end)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
+      if (i < nblk) {                                       // (wave-uniform; no `break`: the loop must unroll, acc[] is registers)
+      const int64_t row0 = m0 + wm * 64 + i * 16;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (row < p.M && cok) {
-            const float y = fmaf(acc[i][j][r] * inv_a, iw, bias);
-            p.Y[row * p.ldy + col] = y;
+      for (int j = 0; j < TJ; ++j) {
+        const bool cok = n0 + wn * WC + j * 16 + r16 < p.Nout;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float y = fmaf(acc[i][j][r] * inv_a, iw[j], bias[j]);
+          stg[(4 * ks + r) * WC + j * 16 + r16] = y;
+          if (row0 + 4 * ks + r < m_end && cok) {
             ymax = fmaxf(ymax, fabsf(y));
-            cs += y;
-            cq += (double)y * y;
+            cs[j] += y;
+            cq[j] += (double)y * y;
           }
         }
       }
-      cs += __shfl_xor(cs, 32, 64);
-      cq += __shfl_xor(cq, 32, 64);
-      if (lane < 32) {
-        colred[(wm * 2 + 0) * BN + cl] = cs;
-        colred[(wm * 2 + 1) * BN + cl] = cq;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int q = 0; q < 16 / RPI; ++q) {
+        const int rr = rrow + RPI * q;
+        const int64_t row = row0 + rr;
+        const float4 v = *reinterpret_cast<const float4*>(stg + rr * WC + rcol);
+        if (row < m_end) {
+          float* dst = p.Y + row * p.ldy + gcol;
+          if (vec_ok && gcol + 3 < p.Nout) {
+            *reinterpret_cast<float4*>(dst) = v;
+          } else {
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              if (gcol + t < p.Nout) dst[t] = vv[t];
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          }
+    }
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int cl = wn * WC + j * 16 + r16;
+      double a = cs[j], b = cq[j];
+      a += __shfl_xor(a, 16, 64);
+      b += __shfl_xor(b, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      b += __shfl_xor(b, 32, 64);
+      if (lane < 16) {
+        colred[(wm * 2 + 0) * BN + cl] = a;
+        colred[(wm * 2 + 1) * BN + cl] = b;
       }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * BN; i += 512) {
+  for (int i = threadIdx.x; i < 2 * BN; i += kSgNT) {
     const int which = i / BN, cl = i % BN, col = n0 + cl;
     if (col < p.Nout && p.stats_out)
       unsafeAtomicAdd(p.stats_out + which * p.Nout + col, colred[(0 * 2 + which) * BN + cl] + colred[(1 * 2 + which) * BN + cl]);
@@ -292,35 +343,48 @@ __global__ __launch_bounds__(512, 1) void gemm_staged_kernel(StagedGemmParams p,
     if (threadIdx.x == 0) {
       float m = wmax[0];
 #pragma unroll
-      for (int w = 1; w < 8; ++w) m = fmaxf(m, wmax[w]);
+      for (int w = 1; w < 12; ++w) m = fmaxf(m, wmax[w]);
       atomicMax(p.amax_y + (blockIdx.x % kAmaxRep), __float_as_uint(m));
     }
   }
 }
 
 // which layers: eval mode (no Dropout here), an input BatchNorm (layers >= 1), many rows (the plan of the in-loop kernel
-// would be 128 x 128 tiles), K a multiple of 32 whose affine fits beside the stages, Nout a multiple of 128
+// would be 128 x 128 tiles), K a multiple of 32 whose affine fits beside the stages, Nout a multiple of 256.  (Narrower
+// layers stay on the in-loop kernel: with 128-column tiles a k-tile is 24 MFMAs per wave and the per-k-tile hand-off
+// dominates -- 100000 x 512 -> 128 measured 0.122 ms here against 0.094 ms in-loop.)
 bool staged_layer(int64_t rows, int K, int Nout) {
   const Knobs& kn = knobs();
   if (kn.gemm_no_staged || kn.gemm_fp32 || kn.gemm_no_f16) return false;
   int sk;
-  return rows >= 4096 && K % 32 == 0 && K >= 64 && K <= 2048 && Nout >= 128 && Nout % 128 == 0 && gemm_plan(rows, K, Nout, &sk) == 2;
+  return rows >= 4096 && K % 32 == 0 && K >= 64 && K <= 2048 && Nout >= 256 && Nout % 256 == 0 && gemm_plan(rows, K, Nout, &sk) == 2;
+}
+
+// Tile height: with M / 128 x Nout / BN tiles on 256 CUs the last round of workgroups can be nearly empty (config 4, layer 1:
+// 1564 tiles = 6.1 rounds, paid as 7).  The height is a launch parameter (a multiple of 16 in [80, 128]; the second row of
+// consumer waves takes bm - 64 rows, and the two waves that share a SIMD always add up to bm): take the one that minimises
+// rounds x height -- 112 rows there: 1786 tiles = 6.98 rounds of 7/8 of the work each.
+int staged_tile_rows(int64_t M, int tiles_n) {
+  int best = kSgBM;
+  int64_t best_cost = -1;
+  for (int bm = kSgBM; bm >= 80; bm -= 16) {
+    const int64_t tiles = (M + bm - 1) / bm * tiles_n, rounds = (tiles + 255) / 256;
+    const int64_t cost = rounds * (bm + 8);              // + 8: a tile's fixed cost (prologue, epilogue) in row equivalents
+    if (best_cost < 0 || cost < best_cost) { best = bm; best_cost = cost; }
+  }
+  return best;
 }
 
 int launch_gemm_staged(const StagedGemmParams& p, hipStream_t s) {
-  if (p.M < 1 || p.K % 32 || p.K > 2048 || p.Nout % 128 || !p.stats_in || !p.amax_a) return 1;
-  const int tiles_m = (int)((p.M + kSgBM - 1) / kSgBM);
-  const bool wide = p.Nout % 256 == 0;
-  const int bn = wide ? 256 : 128, tiles_n = p.Nout / bn;
+  constexpr int bn = 256;
+  if (p.M < 1 || p.K % 32 || p.K < 64 || p.K > 2048 || p.Nout % bn || !p.stats_in || !p.amax_a) return 1;
+  const int tiles_n = p.Nout / bn;
+  const int bm = staged_tile_rows(p.M, tiles_n);
+  const int tiles_m = (int)((p.M + bm - 1) / bm);
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
-  const size_t lds = (size_t)kSgNW * 2 * bn * kSgRowB + (size_t)kSgNA * 2 * kSgAImg + (size_t)(2 * p.K + 4 + 16) * sizeof(float);
-  if (wide) {
-    if (!allow_big_lds(reinterpret_cast<const void*>(gemm_staged_kernel<256>), 160 * 1024)) return MTMC_E_HIP;
-    hipLaunchKernelGGL(gemm_staged_kernel<256>, dim3(grid), dim3(512), lds, s, p, tiles_m, tiles_n);
-  } else {
-    if (!allow_big_lds(reinterpret_cast<const void*>(gemm_staged_kernel<128>), 160 * 1024)) return MTMC_E_HIP;
-    hipLaunchKernelGGL(gemm_staged_kernel<128>, dim3(grid), dim3(512), lds, s, p, tiles_m, tiles_n);
-  }
+  const size_t lds = (size_t)kSgNW * 2 * bn * kSgRowB + (size_t)2 * 2 * kSgAImg + (size_t)(2 * p.K + 4 + 24) * sizeof(float);
+  if (!allow_big_lds(reinterpret_cast<const void*>(gemm_staged_kernel<bn>), 160 * 1024)) return MTMC_E_HIP;
+  hipLaunchKernelGGL(gemm_staged_kernel<bn>, dim3(grid), dim3(kSgNT), lds, s, p, tiles_m, tiles_n, bm);
   return MTMC_OK;
 }
 

@@ -138,7 +138,7 @@ void launch_split_rows(const float* X, int64_t ld, int64_t rows, int K, void* H,
 // hipFuncAttributeMaxDynamicSharedMemorySize, once per (kernel, device); false when HIP refuses (gemm_bn.hip)
 bool allow_big_lds(const void* fn, int bytes);
 bool presplit_layer0(int64_t rows, int K, int Nout);   // many rows, K % 64 == 0, K <= 2048, not disabled (MTMC_GEMM_NO_PRESPLIT)
-int launch_gemm_presplit(const SplitGemmParams& p, hipStream_t s, int variant = 0);   // 0 ok, 1 unsupported shape
+int launch_gemm_presplit(const SplitGemmParams& p, hipStream_t s);   // 0 ok, 1 unsupported shape, MTMC_E_HIP
 
 void launch_prep(const PrepParams& p, hipStream_t s);
 void launch_enc2(const EdgeEncParams& enc, const float* attr, int64_t n_edges, double e_total, double* stat_enc2,

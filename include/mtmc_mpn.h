@@ -237,15 +237,24 @@ int32_t mtmc_mlp_layer_forward(const mtmc_layer* layer, const float* x, int64_t 
 int32_t mtmc_linear_raw(const float* A, int64_t lda, const float* W, const float* bias, float* Y, int64_t M, int32_t K,
                         int32_t N, uint32_t* scratch, double* stats, void* stream);
 
+/* One encoder layer >= 1 as the forward runs it on graphs with >= 4096 nodes (csrc/gemm_staged.hip):
+ * Y[M][N] = relu(bn(A))[M][K] . W[N][K]^T + bias, bn = BatchNorm1d with batch statistics given as stats_in = f64 column
+ * sum[K] | sum of squares[K] over `count` rows, and gamma_in / beta_in [K] (reference models/mlp.py:14-27: the previous
+ * group's BatchNorm + ReLU fused into this Linear).  K a multiple of 32 in [64, 2048], N a multiple of 256.
+ * work: >= 4*N*K + 4*N + 256 bytes; scratch: u32[48]; stats: f64[2*N] column sum / sum of squares of Y, or NULL. */
+int32_t mtmc_linear_staged_raw(const float* A, int64_t lda, const double* stats_in, const float* gamma_in,
+                               const float* beta_in, double count, const float* W, const float* bias, float* Y, int64_t M,
+                               int32_t K, int32_t N, void* work, uint64_t work_bytes, uint32_t* scratch, double* stats,
+                               void* stream);
+
 /* The pre-split twin of mtmc_linear_raw (csrc/gemm_presplit.hip; what the forward runs for encoder layer 0 of graphs
  * with >= 4096 nodes): A and W are first split into fp16 pairs with one power-of-two scale per row, stored k-tile-major
  * (work: >= 4*M*K + 4*N*K + 4*(M+N) + 1024 bytes of device memory), then multiplied by a plain fp16 MFMA GEMM fed by
- * LDS-DMA.  K a multiple of 64, K <= 2048.  variant >= 0 picks the kernel (11: the one the forward uses; 0, 2, 3, 4, 8,
- * 9, 10: alternates kept for A/B; 12-17: timing experiments); variant < 0 reuses the planes already in
- * `work` with variant -v-1. */
+ * LDS-DMA.  K a multiple of 64, K <= 2048.  reuse_planes != 0: the planes a previous call left in `work` are multiplied
+ * again (times the GEMM alone).  (The kernels this one was chosen against are not in this library: csrc/lab/.) */
 int32_t mtmc_linear_presplit_raw(const float* A, int64_t lda, const float* W, const float* bias, float* Y, int64_t M,
                                  int32_t K, int32_t N, void* work, uint64_t work_bytes, uint32_t* scratch,
-                                 double* stats, int32_t variant, void* stream);
+                                 double* stats, int32_t reuse_planes, void* stream);
 
 /* ---- graph construction (SURVEY.md 8(f)-1,2; replaces reference inference.py:402-456 / train.py:316-342) ----
  * feats [N][F] raw per-tracklet features -> x_out [N][F] (column-normalised like F.normalize(dim=0) if l2norm),

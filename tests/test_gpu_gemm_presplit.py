@@ -1,6 +1,7 @@
-"""Experimental pre-split GEMM (csrc/gemm_presplit.hip, mtmc_linear_presplit_raw) against float64: every tile /
-pipeline variant, ragged edges, rows of very different magnitude, zero rows.  Same bound as the in-loop split kernel:
-|err| <= 3e-7 * (sum_k |a||w| + |b|)."""
+"""Pre-split first-layer GEMM against float64: the product kernel (csrc/gemm_presplit.hip, mtmc_linear_presplit_raw) and
+every A/B variant of the kernel laboratory (csrc/lab/presplit_lab.hip, libmtmc_lab.so: mtmc_lab_linear_presplit_raw) --
+ragged edges, rows of very different magnitude, zero rows.  Same bound as the in-loop split kernel:
+|err| <= 3e-7 * (sum_k |a||w| + |b|).  `variant`: "product" or a laboratory variant number (negative: reuse the planes)."""
 import pytest
 import torch
 
@@ -16,15 +17,20 @@ def _run(lib, A, W, b, variant, work=None):
         work = torch.empty(4 * M * K + 4 * N * K + 4 * (M + N) + 1024, dtype=torch.uint8, device="cuda")
     scr = torch.zeros(48, dtype=torch.int32, device="cuda")
     st = torch.empty(2 * N, dtype=torch.float64, device="cuda")
-    _lib.check(lib.mtmc_linear_presplit_raw(A.data_ptr(), A.stride(0), W.data_ptr(), b.data_ptr(), Y.data_ptr(), M, K, N,
-                                            work.data_ptr(), work.numel(), scr.data_ptr(), st.data_ptr(), variant,
-                                            torch.cuda.current_stream().cuda_stream))
+    args = (A.data_ptr(), A.stride(0), W.data_ptr(), b.data_ptr(), Y.data_ptr(), M, K, N, work.data_ptr(), work.numel(),
+            scr.data_ptr(), st.data_ptr())
+    if variant in ("product", "product-reuse"):
+        _lib.check(lib.mtmc_linear_presplit_raw(*args, 1 if variant == "product-reuse" else 0, torch.cuda.current_stream().cuda_stream))
+    else:
+        rc = _lib.load_lab().mtmc_lab_linear_presplit_raw(*args, variant, torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"mtmc_lab_linear_presplit_raw: code {rc}")
     torch.cuda.synchronize()
     return Y, st, scr[32:48].view(torch.float32).max().item(), work
 
 
 @pytest.mark.parametrize("shape", [(129, 64, 128), (300, 512, 130), (777, 2048, 1024), (1030, 1024, 520)])
-@pytest.mark.parametrize("variant", [0, 2, 3, 4, 8, 9, 10, 11])
+@pytest.mark.parametrize("variant", ["product", 0, 2, 3, 4, 8, 9, 10, 11])
 def test_presplit_matches_float64(shape, variant):
     from mtmc_mpn import _lib
     lib = _lib.load()
@@ -54,9 +60,11 @@ def test_presplit_strided_rows_and_reused_planes():
     A = big[:, :K]                                           # row stride K + 64
     W = torch.randn(N, K, device="cuda", generator=g)
     b = torch.zeros(N, device="cuda")
-    Y0, _, _, work = _run(lib, A, W, b, 0)
-    Y1, _, _, _ = _run(lib, A, W, b, -1, work)               # variant -1: planes already in `work`, variant 0
+    Y0, _, _, work = _run(lib, A, W, b, "product")
+    Y1, _, _, _ = _run(lib, A, W, b, "product-reuse", work)  # planes already in `work`
     assert torch.equal(Y0, Y1)
+    Y2, _, _, _ = _run(lib, A, W, b, -1, work)               # laboratory variant 0 on the same planes
+    assert (Y2 - Y0).abs().max().item() <= 1e-5 * Y0.abs().max().item()
     ref = A.double() @ W.double().t()
     assert ((Y0.double() - ref).abs() / (A.double().abs() @ W.double().abs().t())).max().item() < 3e-7
 
@@ -68,11 +76,11 @@ def test_presplit_rejects_bad_shapes():
     W = torch.randn(8, 96, device="cuda")
     b = torch.zeros(8, device="cuda")
     with pytest.raises(RuntimeError):
-        _run(lib, A, W, b, 0)                                # K % 64 != 0
+        _run(lib, A, W, b, "product")                        # K % 64 != 0
     A = torch.randn(8, 64, device="cuda")
     W = torch.randn(8, 64, device="cuda")
     with pytest.raises(RuntimeError):
-        _run(lib, A, W, b, 0, work=torch.empty(64, dtype=torch.uint8, device="cuda"))   # work too small
+        _run(lib, A, W, b, "product", work=torch.empty(64, dtype=torch.uint8, device="cuda"))   # work too small
 
 
 @pytest.mark.parametrize("M,K", [(77, 64), (1030, 512), (4097, 2048)])
@@ -86,7 +94,7 @@ def test_plane_layout_and_split_are_as_documented(M, K):
     A = (torch.randn(M, K, generator=g) * torch.logspace(-3, 3, M).unsqueeze(1)).cuda()
     A[M // 2] = 0.0                                              # a zero row: scale stays finite
     W = torch.randn(40, K, generator=g).cuda()
-    _, _, _, work = _run(lib, A, W, torch.zeros(40, device="cuda"), 0)
+    _, _, _, work = _run(lib, A, W, torch.zeros(40, device="cuda"), "product")
     planes = work[:M * K * 4].view(torch.float16).view(2, K // 32, M, 4, 8)      # [piece][k-tile][row][slot][8]
     inv = work[M * K * 4:M * K * 4 + M * 4].view(torch.float32)
     r = torch.arange(M, device="cuda")

@@ -45,8 +45,9 @@ def run(kind, seconds=4.0):
     st = torch.empty(2 * N, dtype=torch.float64, device="cuda")
 
     def gemm(variant):
-        _lib.check(lib.mtmc_linear_presplit_raw(A.data_ptr(), K, W.data_ptr(), b.data_ptr(), Y.data_ptr(), M, K, N,
-                                                work.data_ptr(), work.numel(), scr.data_ptr(), st.data_ptr(), variant, s))
+        rc = _lib.load_lab().mtmc_lab_linear_presplit_raw(A.data_ptr(), K, W.data_ptr(), b.data_ptr(), Y.data_ptr(), M, K, N,
+                                                          work.data_ptr(), work.numel(), scr.data_ptr(), st.data_ptr(), variant, s)
+        assert rc == 0, rc
     gemm(9)
     torch.cuda.synchronize()
     stop, samples = threading.Event(), []

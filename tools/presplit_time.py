@@ -11,14 +11,15 @@ import torch  # noqa: E402
 from mtmc_mpn import _lib  # noqa: E402
 
 lib = _lib.load()
+lab = _lib.load_lab()            # the A/B variants live in the kernel laboratory (csrc/lab/, libmtmc_lab.so)
 VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "0,9").split(",")]
 s = torch.cuda.current_stream().cuda_stream
 
 
 def run(M, K, N, variant, A, W, b, Y, work, scr, st):
-    rc = lib.mtmc_linear_presplit_raw(A.data_ptr(), K, W.data_ptr(), b.data_ptr(), Y.data_ptr(), M, K, N, work.data_ptr(),
-                                      work.numel(), scr.data_ptr(), st.data_ptr(), variant, s)
-    assert rc == 0, (rc, lib.mtmc_last_error())
+    rc = lab.mtmc_lab_linear_presplit_raw(A.data_ptr(), K, W.data_ptr(), b.data_ptr(), Y.data_ptr(), M, K, N, work.data_ptr(),
+                                          work.numel(), scr.data_ptr(), st.data_ptr(), variant, s)
+    assert rc == 0, rc
 
 
 def check(M, K, N):
