@@ -108,18 +108,23 @@ def pmc_traffic(workload, kernel):
     return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0
 
 
-def encoder_kernel(n_rows, layer, idx=None):
-    """Which GEMM kernel csrc/gemm_bn.hip:gemm_plan / csrc/gemm_presplit.hip:presplit_layer0 pick for an encoder layer
-    (mirrors their rules)."""
-    big = ((n_rows + 127) // 128) * ((layer.out_dim + 127) // 128) >= 256 and layer.out_dim >= 128
+GEMM_KERNEL_NAMES = {_lib.GEMM_GENERIC: "linear_generic_kernel", _lib.GEMM_INLOOP_64: "gemm_bn_f16x3_kernel",
+                     _lib.GEMM_INLOOP_128: "gemm_bn_f16x3_kernel", _lib.GEMM_PRESPLIT_256: "gemm_f16p_m16_kernel",
+                     _lib.GEMM_STAGED_128: "gemm_staged_kernel"}
+
+
+def encoder_kernels(model, n, e):
+    """Kernel name per node-encoder layer, asked of the library itself (mtmc_mpn_plan_call) instead of mirrored here."""
+    from mtmc_mpn import engine
+    eng = model._engine or engine.ForwardEngine(model)
+    ids = eng.plan(n, e).enc_kernel
+    names = [GEMM_KERNEL_NAMES[i] for i in ids]
     if os.environ.get("MTMC_GEMM_FP32"):
-        return "gemm_bn_kernel"
-    if os.environ.get("MTMC_GEMM_NO_F16"):
-        return "gemm_bn_bf16x6_kernel" if big else "gemm_bn_kernel"
-    if idx == 0 and big and n_rows >= 4096 and layer.in_dim % 64 == 0 and layer.in_dim <= 2048 \
-            and not os.environ.get("MTMC_GEMM_NO_PRESPLIT"):
-        return "gemm_f16p_m16_kernel"      # layer 0 of many-row graphs: pre-split operands (+ split_rows_kernel in PH_BEGIN)
-    return "gemm_bn_f16x3_kernel"
+        names = ["gemm_bn_kernel" if i != _lib.GEMM_GENERIC else n_ for i, n_ in zip(ids, names)]
+    elif os.environ.get("MTMC_GEMM_NO_F16"):
+        names = [("gemm_bn_bf16x6_kernel" if i == _lib.GEMM_INLOOP_128 else "gemm_bn_kernel") if i != _lib.GEMM_GENERIC else n_
+                 for i, n_ in zip(ids, names)]
+    return names
 
 
 def phase_cost(ph, arg, spec, n, e):
@@ -259,30 +264,32 @@ def cpu_baseline(name, params, sd, data, max_seconds=25.0):
         avail = os.cpu_count() or 1
     torch.set_num_threads(max(1, min(avail, 16)))
     e_full = data.edge_index.shape[1]
-    if e_full <= 1_000_000:
+    if e_full <= 20_000_000:                 # the headline graph and config 4: the WHOLE workload ("configs 1-4 in full")
         x, ei, ea = data.x.cpu(), data.edge_index.cpu(), data.edge_attr.cpu()
         sample = "full workload"
-    else:
-        scale = 10 if e_full <= 20_000_000 else 100
+    else:                                    # config 5 would need ~80 GB of host intermediates and minutes per forward
+        scale = 100
         d = graphs.stress_graph(data.x.shape[0] // scale, e_full // (2 * scale), seed=4)
         x, ei, ea = d.x, d.edge_index, d.edge_attr
         sample = f"same recipe at 1/{scale} scale: {x.shape[0]} nodes / {ei.shape[1]} edges (edges/s is size-normalised)"
+    # ~8 s per forward at config 4 on 16 threads: one warm-up and two timed forwards there, 3 + 10 on the headline graph
+    n_warm, n_max = (1, 3) if e_full > 1_000_000 else (3, 13)
     sd_cpu = {k: v.cpu() for k, v in sd.items()}
     times = []
     with torch.no_grad():
         t_start = time.perf_counter()
-        for i in range(13):
+        for i in range(n_max):
             t0 = time.perf_counter()
             mpn_oracle.forward(sd_cpu, copy.deepcopy(params), ARCH, x, ei, ea)
             dt = time.perf_counter() - t0
-            if i >= 3:
+            if i >= n_warm:
                 times.append(dt)
             if time.perf_counter() - t_start > max_seconds and len(times) >= 2:
                 break
     times.sort()
     med = times[len(times) // 2]
     return {"value": ei.shape[1] / med, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{sample}; median of {len(times)} forwards after 3 warm-ups, {med * 1e3:.1f} ms each",
+            "sample": f"{sample}; median of {len(times)} forwards after {n_warm} warm-up(s), {med * 1e3:.1f} ms each",
             "host_cpu_count": os.cpu_count()}
 
 
@@ -309,8 +316,10 @@ def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
     spec = model.spec
     # dominant kernel = the kernel NAME with the largest summed time (all its launches in a step, the same
     # granularity as a rocprofv3 --stats row); phases that launched nothing (un-split combine) are skipped
+    enc_names = encoder_kernels(model, n, e)
+
     def kernel_of(ph, arg):
-        return encoder_kernel(n, spec.enc_node[arg], arg) if ph == _lib.PH_NODE_ENC else PHASE_NAMES[ph]
+        return enc_names[arg] if ph == _lib.PH_NODE_ENC else PHASE_NAMES[ph]
     by_kind = {}
     for (ph, arg), t in zip(seq, ms):
         if ph == _lib.PH_NODE_COMBINE and t < 2e-3:
@@ -323,7 +332,7 @@ def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
     bound = kinds[0][0]
     work = sum(w for _, w in kinds) / len(kinds)
     peak_note = None
-    if bound == "mfma" and dom_key in ("gemm_bn_f16x3_kernel", "gemm_f16p_m16_kernel"):
+    if bound == "mfma" and dom_key in ("gemm_bn_f16x3_kernel", "gemm_f16p_m16_kernel", "gemm_staged_kernel"):
         achieved, peak, unit = work / (avg_ms * 1e-3) / 1e12, MFMA_BF16_PEAK_TFLOPS / 3.0, "TFLOP/s"
         peak_note = ("algorithmic fp32 flops (2*M*N*K) against the fp16 dense MFMA peak (= the bf16 one) / 3: the kernel "
                      "reaches fp32 accuracy with three fp16 products per fp32 product")

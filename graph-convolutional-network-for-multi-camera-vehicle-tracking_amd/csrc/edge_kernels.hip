@@ -630,14 +630,23 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
       }
     };
     const int64_t c_end = min(n_chunks, (span + 1) * span_c);
-    // e' / row ids are fetched one chunk ahead; the Q rows of the chunk's first and last row (all of its rows at the
-    // degrees this kernel runs at) are requested as soon as its row ids are there, ahead of the classifier and the MFMAs
-    float4 ev_n = make_float4(0.f, 0.f, 0.f, 0.f);
-    int rw_n = -1;
-    auto fetch = [&](int64_t chunk) {            // ALWAYS two loads (the counted wait below relies on it): clamped address
+    // A three-deep software pipeline of PLAIN loads (the compiler counts every one of them, so its own s_waitcnt is exact;
+    // round 2 issued the Q lookups from inline asm behind a hand-counted s_waitcnt vmcnt(2)):
+    //   chunk c + 2: e' / row ids requested                                  (ev_3, rw_3)
+    //   chunk c + 1: row ids have landed -> the Q rows of its first and last row requested   (all of its rows at the degrees
+    //                this kernel runs at; other rows of a chunk are looked up on demand)
+    //   chunk c    : everything is in registers -> classifier, MFMAs, sums
+    // so a k-iteration waits once, at its top, for loads issued a whole iteration earlier, and the table lookups' latency
+    // (the Q table lives in L2 / Infinity Cache: 0.3-1 us under load) no longer sits between a chunk's loads and its MFMAs.
+    auto fetch = [&](int64_t chunk, float4& ev_o, int& rw_o) {    // clamped address: chunks past the end re-read the last edge
       const int64_t e = min(chunk * 64 + lane, p.n_edges - 1);
-      ev_n = reinterpret_cast<const float4*>(p.e_out)[e];
-      rw_n = p.row32[e];
+      ev_o = reinterpret_cast<const float4*>(p.e_out)[e];
+      rw_o = p.row32[e];
+    };
+    auto rows_of = [&](int rw_raw, int64_t chunk, int& first, int& last) {   // first / last row of a chunk (wave-uniform)
+      const int nv = (int)min((int64_t)64, p.n_edges - chunk * 64);
+      first = __builtin_amdgcn_readfirstlane(rw_raw);
+      last = __builtin_amdgcn_readfirstlane(__shfl(rw_raw, (nv > 0 ? nv : 1) - 1, 64));
     };
     int qa_row = -1, qb_row = -1;
     float qa = 0.f, qb = 0.f;
@@ -665,37 +674,35 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
       return s0 + s1;
     };
     const int64_t c0_chunk = span * span_c;
-    fetch(c0_chunk);
+    float4 ev_1, ev_2;
+    int rw_1, rw_2;
+    fetch(c0_chunk, ev_1, rw_1);
+    rows_of(rw_1, c0_chunk, qa_row, qb_row);
+    qa = p.Q[(int64_t)qa_row * kH + k];
+    qb = p.Q[(int64_t)qb_row * kH + k];
+    fetch(c0_chunk + 1, ev_2, rw_2);
     for (int64_t chunk = c0_chunk; chunk < c_end; ++chunk) {
+      // ---- chunk + 1: its row ids were requested one iteration ago; request its Q rows.  chunk + 2: request the stream.
+      int qa_row_2, qb_row_2;
+      rows_of(rw_2, chunk + 1, qa_row_2, qb_row_2);
+      const float qa_2 = p.Q[(int64_t)qa_row_2 * kH + k];
+      const float qb_2 = p.Q[(int64_t)qb_row_2 * kH + k];
+      float4 ev_3;
+      int rw_3;
+      fetch(chunk + 2, ev_3, rw_3);
+      // ---- chunk: all in registers
       const int64_t e = chunk * 64 + lane;
       const bool valid = e < p.n_edges;
       float4 ev = make_float4(0.f, 0.f, 0.f, 0.f);
       if (valid) {
-        ev = ev_n;
+        ev = ev_1;
         if (p.lazy_e) {
           ev.x = fmaxf(fmaf(ev.x, s1[0], t1[0]), 0.f); ev.y = fmaxf(fmaf(ev.y, s1[1], t1[1]), 0.f);
           ev.z = fmaxf(fmaf(ev.z, s1[2], t1[2]), 0.f); ev.w = fmaxf(fmaf(ev.w, s1[3], t1[3]), 0.f);
         }
       }
-      const int rw = valid ? rw_n : -1;
+      const int rw = valid ? rw_1 : -1;
       const int n_valid = (int)min((int64_t)64, p.n_edges - chunk * 64);      // scalar
-      qa_row = __builtin_amdgcn_readfirstlane(rw);
-      qb_row = __builtin_amdgcn_readfirstlane(__shfl(rw, n_valid - 1, 64));
-      // The Q lookups of this chunk's first / last row and the NEXT chunk's stream loads are in flight together.  Loads
-      // return in order, so the lookups go out first and are waited for with a COUNTED s_waitcnt that leaves the two
-      // prefetch loads outstanding -- otherwise the stream's HBM latency would sit in every iteration.  They are issued
-      // from inline asm because hipcc would wait vmcnt(0) for a plain load's result here (control flow in between).
-      {
-        const float* pa = p.Q + (int64_t)qa_row * kH + k;
-        const float* pb = p.Q + (int64_t)qb_row * kH + k;
-        // (the s_mov with the 0xc0de0001 literal marks the pair for tools/check_isa.py, rule COUNTED-WAIT: at build time the
-        // lint verifies on the code object that exactly two vector loads, no store and no touch of %0 / %1 sit between
-        // here and the marked wait below -- the things this sequence relies on and the compiler knows nothing about)
-        int mark;
-        asm volatile("s_mov_b32 %2, 0xc0de0001\n\tglobal_load_dword %0, %3, off\n\tglobal_load_dword %1, %4, off"
-                     : "=&v"(qa), "=&v"(qb), "=s"(mark) : "v"(pa), "v"(pb) : "memory");
-      }
-      fetch(chunk + 1);
       float lg0 = 0.f, lg1 = 0.f;
       if (want_logits && p.n_classes == 2) {                    // classifier on this edge (mpn.py:291-292): arithmetic now,
         // two scalar FMA chains, kept apart: paired up by the SLP vectoriser they become v_pk_fma_f32 with op_sel,
@@ -734,12 +741,7 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
           two_rows_max[g] = (ma[g] | mb[g]) == gmv[g];
         }
       }
-      // Q lookups done (the two prefetch loads may still be in flight); stores only from here on -- they share the counter
-      {
-        int mark;
-        asm volatile("s_mov_b32 %2, 0xc0de0002\n\ts_waitcnt vmcnt(2)" : "+v"(qa), "+v"(qb), "=s"(mark) : : "memory");
-      }
-      if (want_logits && valid) {                                // ... the store after the counted wait
+      if (want_logits && valid) {
         if (p.n_classes == 2) {
           reinterpret_cast<float2*>(p.logits)[e] = make_float2(lg0, lg1);
         } else {
@@ -838,6 +840,11 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
           }
         }
       }
+      // rotate the pipeline
+      ev_1 = ev_2; rw_1 = rw_2;
+      ev_2 = ev_3; rw_2 = rw_3;
+      qa_row = qa_row_2; qb_row = qb_row_2;
+      qa = qa_2; qb = qb_2;
     }
     flush();
   }
@@ -943,7 +950,8 @@ void launch_pass_c(const RoundParams& p0, hipStream_t s) {
   p.mfma_c = plan_pass_c(p.agg, p.det != 0, p.drop_n.on != 0, p.n_edges, p.avg_degree);
   if (p.mfma_c) {
     // many edges: a resident grid (the block prologue -- 74 replicated statistics, one BatchNorm affine per channel -- is
-    // paid once per block, so blocks live long) whose waves take short spans round-robin (~6 spans per wave at config 4);
+    // paid once per block, so blocks live long) whose waves take short spans round-robin (~6 spans per wave at config 4;
+    // 768 / 1024 / 1536 / 2048 blocks: 114 / 138 / 120 / 122 us per launch there -- the grid that is exactly resident wins);
     // few edges: one 64-edge chunk per wave, as many waves as there are chunks
     const int span_env = knobs().pass_c_span, max_blocks = knobs().pass_c_blocks;
     const int span_c = span_env > 0 ? span_env : (p.mfma_c == 2 ? 1 : 8);

@@ -13,8 +13,8 @@ static Knobs read_knobs() {
   k.pass_c_walk = on("MTMC_PASS_C_WALK");
   k.pass_c_small_min = num("MTMC_PASS_C_SMALL_MIN", 32768);
   k.pass_c_span = (int)num("MTMC_PASS_C_SPAN", 0);
-  k.pass_c_blocks = (int)num("MTMC_PASS_C_BLOCKS", 256 * 6);
-  if (k.pass_c_blocks < 1) k.pass_c_blocks = 256 * 6;
+  k.pass_c_blocks = (int)num("MTMC_PASS_C_BLOCKS", 256 * 3);      // what is resident: 130 VGPRs -> 3 waves per SIMD = 3 blocks per CU
+  if (k.pass_c_blocks < 1) k.pass_c_blocks = 256 * 3;
   k.gemm_fp32 = on("MTMC_GEMM_FP32");
   k.gemm_no_f16 = on("MTMC_GEMM_NO_F16");
   k.gemm_no_presplit = on("MTMC_GEMM_NO_PRESPLIT");

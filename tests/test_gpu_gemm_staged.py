@@ -56,7 +56,9 @@ def test_staged_matches_float64(shape):
     W[N // 3] *= 1e-3                                          # rows of very different magnitude: per-row weight scales
     b = torch.randn(N, device="cuda", generator=g)
     Y, st, ymax, st_in = _run(A, gamma, beta, W, b)
-    a, ref, bound = _ref(A, st_in, gamma, beta, W, b, float(M))
+    # column 1 (beta = 30) dominates every dot product: with few terms nothing averages and the budget is the worst case of
+    # two truncated two-piece operands (2^-20 each); from K = 512 on the statistical 5e-7 holds as for the other kernels
+    a, ref, bound = _ref(A, st_in, gamma, beta, W, b, float(M), split=2.0 ** -19 if K < 512 else 5e-7)
     assert torch.isfinite(Y).all()
     assert (a[:, 0] == 0).all()
     err = ((Y.double() - ref).abs() / bound).max().item()

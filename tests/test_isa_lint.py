@@ -3,9 +3,9 @@ inline-asm sequences in the shape their correctness depends on.
 
 PK-OPSEL: packed-fp32 ops whose low lane selects a source's high dword, inside a kernel with MFMAs, returned 0 in lanes 48-63
 under two waves per SIMD -- the root cause of round 1's "fp16 conversion" failure.  LDS-DMA-M0: every `global_load_lds` right
-behind its own `s_mov_b32 m0` (the compiler does not know the asm writes m0).  COUNTED-WAIT: between the two marked asm
-`global_load_dword` of pass_c_mfma_kernel and their `s_waitcnt vmcnt(N)` exactly N vector loads, no store, no touch of the
-destination registers.  The compiler creates / could break all three by itself, so the check is on the shipped code objects,
+behind its own `s_mov_b32 m0` (the compiler does not know the asm writes m0).  COUNTED-WAIT: between two marked asm
+`global_load_dword` and their hand-counted `s_waitcnt vmcnt(N)` exactly N vector loads, no store, no touch of the destination
+registers (round 2's pass_c_mfma_kernel had such a sequence; round 3 replaced it by plain loads, the rule stays).  The compiler creates / could break all three by itself, so the check is on the shipped code objects,
 not the source -- and each rule is shown here to fire on a patched listing."""
 import importlib.util
 import os
@@ -35,11 +35,12 @@ def test_shipped_library_passes_isa_lint():
     kernels = list(ci.kernels_of(_lib.LIB_PATH))
     assert len(kernels) > 40 and any("gemm_bn_f16x3" in n for n, _ in kernels)
     assert ci.violations_in(kernels) == []
-    # the rules had something to look at: LDS-DMA in the two pre-split GEMMs, one counted-wait region in the matrix-core pass C
+    # the LDS-DMA rule had something to look at: the two pre-split GEMMs.  (Round 3 rewrote pass_c_mfma_kernel as a software
+    # pipeline of plain loads, so the product has no hand-counted wait left; the COUNTED-WAIT rule stays for any kernel
+    # that marks one, and is exercised on patched listings below.)
     dma = {n for n, b in kernels for i in b if i.startswith("global_load_lds_")}
     assert any("gemm_f16p_m16" in n for n in dma) and any("gemm_staged" in n for n in dma)
-    marked = [n for n, b in kernels for i in b if ci.MARK_PAIR in i]
-    assert marked and all("pass_c_mfma" in n for n in marked)
+    assert not [n for n, b in kernels for i in b if ci.MARK_PAIR in i or ci.MARK_WAIT in i]
 
 
 def test_product_library_ships_no_laboratory_kernels_and_no_scratch():

@@ -13,8 +13,9 @@ with `s_mov_b32 m0, ...` -- a register the compiler believes reserved for its ow
 Every such instruction must be preceded by its OWN `s_mov_b32 m0`, with nothing but `s_nop` in between (nothing that reads or
 writes m0 can have been scheduled, or emitted by the compiler, between the two).
 
-Rule COUNTED-WAIT (csrc/edge_kernels.hip, pass_c_mfma_kernel): two `global_load_dword` issued from inline asm are waited
-for with a COUNTED `s_waitcnt vmcnt(N)` that leaves the N younger prefetch loads in flight.  That is only right if, between
+Rule COUNTED-WAIT (for any kernel that marks such a sequence; round 2's pass_c_mfma_kernel did, round 3 rewrote it with plain
+loads): two `global_load_dword` issued from inline asm are waited for with a COUNTED `s_waitcnt vmcnt(N)` that leaves the N
+younger prefetch loads in flight.  That is only right if, between
 the pair and the wait, EXACTLY N vector-memory loads were issued, no vector-memory store or atomic (they share the counter),
 and no instruction touches the pair's destination VGPRs (a register copy made before the wait would be stale).  The asm marks
 the two places with `s_mov_b32 sX, 0xc0de0001` (before the pair) and `s_mov_b32 sX, 0xc0de0002` (before the wait); the rule
