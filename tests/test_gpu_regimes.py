@@ -155,3 +155,51 @@ def test_max_aggregation_and_reattach_at_tracker_scale(tracker):
         got, h = _gpu(m.cuda(), tracker)
         want64, h64 = _oracle(sd, params, tracker)
         _check(got, h, want64, h64, str(over))
+
+
+# ---- both sides of every dispatch threshold -----------------------------------------------------------------------------
+# The library switches kernels at: 4096 node rows (pre-split layer 0 vs the in-loop kernel; 8192: role-split layer 1), 524 288
+# edges (edges per thread, lazy e', which pass-C combination), 32 768 edges and 24 edges per source row (matrix-core pass C
+# or the walk).  A graph just below and just above each of them must give the oracle's answer, and the plan query must
+# say the two sides really take different kernels (otherwise the test tests nothing).
+
+def _random_sorted_graph(n, pairs, seed):
+    d = graphs.stress_graph(n, pairs, seed=seed)
+    return types.SimpleNamespace(x=d.x, edge_index=d.edge_index, edge_attr=d.edge_attr)
+
+
+THRESHOLDS = [
+    # (name, graph below, graph above, plan attribute that must differ)
+    ("4096 node rows", (4000, 60_000), (4200, 60_000), "enc_kernel"),
+    ("524288 edges", (3000, 255_000), (3000, 270_000), "edges_per_thread"),
+    ("32768 edges", (500, 15_000), (500, 18_000), "pass_c"),
+    ("24 edges per source row", (2000, 22_000), (2000, 26_000), "pass_c"),
+]
+
+
+@pytest.mark.parametrize("name,below,above,attr", THRESHOLDS, ids=[t[0] for t in THRESHOLDS])
+def test_both_sides_of_a_dispatch_threshold(name, below, above, attr):
+    m, sd, params = _model(2, 2)
+    eng = engine.ForwardEngine(m)
+    plans = []
+    for i, (n, pairs) in enumerate((below, above)):
+        d = _random_sorted_graph(n, pairs, seed=40 + i)
+        plans.append(getattr(eng.plan(n, d.edge_index.shape[1]), attr))
+        got, h = _gpu(m.cuda(), d, transposed_view=False)
+        want64, h64 = _oracle(sd, params, d)
+        _check(got, h, want64, h64, f"{name}: N={n} E={d.edge_index.shape[1]}")
+        m.cpu()
+    assert plans[0] != plans[1], f"{name}: both graphs take the same kernels ({attr} = {plans[0]})"
+
+
+@pytest.mark.parametrize("n", [8192, 8300, 9001, 12345])
+def test_many_row_encoder_with_ragged_tile_heights(n):
+    """The role-split layer-1 kernel picks its tile height (80..128 rows) per launch and the pre-split layer-0 kernel runs
+    256-row tiles: node counts that leave ragged last tiles, at a size the CPU oracle evaluates in seconds."""
+    m, sd, params = _model(1, 1)
+    plan = engine.ForwardEngine(m).plan(n, 2 * 40_000)
+    assert plan.enc_kernel[:2] == [_lib.GEMM_PRESPLIT_256, _lib.GEMM_STAGED_128]
+    d = _random_sorted_graph(n, 40_000, seed=n)
+    got, h = _gpu(m.cuda(), d, transposed_view=False)
+    want64, h64 = _oracle(sd, params, d)
+    _check(got, h, want64, h64, f"N={n}")
