@@ -203,3 +203,16 @@ def test_many_row_encoder_with_ragged_tile_heights(n):
     got, h = _gpu(m.cuda(), d, transposed_view=False)
     want64, h64 = _oracle(sd, params, d)
     _check(got, h, want64, h64, f"N={n}")
+
+
+@pytest.mark.parametrize("over", [dict(reattach_initial_nodes=True), dict(reattach_initial_nodes=True, reattach_initial_edges=True),
+                                  dict(node_agg_fn="mean"), dict(node_agg_fn="max")],
+                         ids=["reattach_nodes", "reattach_both", "mean", "max"])
+def test_many_node_variants(over):
+    """The matrix-core projection kernel (node rows >= 4096) in its 64-wide [h0 | h] form, with mean aggregation's 1/deg
+    scaling on the way in, and beside the walk (max aggregation) -- the fixtures cover these variants at <= 450 nodes only."""
+    m, sd, params = _model(3, 2, **over)
+    d = _random_sorted_graph(4500, 70_000, seed=77)
+    got, h = _gpu(m.cuda(), d, transposed_view=False)
+    want64, h64 = _oracle(sd, params, d)
+    _check(got, h, want64, h64, str(over))
