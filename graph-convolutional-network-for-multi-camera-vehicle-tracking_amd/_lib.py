@@ -57,7 +57,7 @@ class Plan(C.Structure):
                 ("avg_degree", C.c_double)]
 
 
-GEMM_GENERIC, GEMM_INLOOP_64, GEMM_INLOOP_128, GEMM_PRESPLIT_256, GEMM_STAGED_128 = range(5)
+GEMM_GENERIC, GEMM_INLOOP_64, GEMM_INLOOP_128, GEMM_PRESPLIT_256, GEMM_STAGED_128, GEMM_ROWS_16 = range(6)
 PASS_C_WALK, PASS_C_MFMA_SORTED, PASS_C_MFMA_ANY = range(3)
 
 # statistics blocks (include/mtmc_mpn.h): replicas x stride doubles each

@@ -83,9 +83,10 @@ int32_t mtmc_mpn_plan_call(const mtmc_mpn_model* model, const mtmc_mpn_call* cal
     const int cfg = rows > 0 ? mtmc::gemm_plan(rows, L.in_dim, L.out_dim, &sk_here) : 0;
     const bool slab = sk_here > 1 && (size_t)sk_here * rows <= (size_t)(sk_full > 1 ? sk_full : 0) * c->n_nodes;   // run_phase
     const bool stg = l >= 1 && !c->training && mtmc::staged_layer(c->n_nodes, L.in_dim, L.out_dim) && mtmc::staged_layer(rows, L.in_dim, L.out_dim);
-    out->enc_kernel[l] = (l == 0 && pre0) ? MTMC_GEMM_PRESPLIT_256 : stg ? MTMC_GEMM_STAGED_128 : cfg == 2 ? MTMC_GEMM_INLOOP_128 : cfg == 1 ? MTMC_GEMM_INLOOP_64
+    const bool rws = l >= 1 && !c->training && mtmc::rows_layer(c->n_nodes, L.in_dim, L.out_dim) && mtmc::rows_layer(rows, L.in_dim, L.out_dim);
+    out->enc_kernel[l] = (l == 0 && pre0) ? MTMC_GEMM_PRESPLIT_256 : stg ? MTMC_GEMM_STAGED_128 : rws ? MTMC_GEMM_ROWS_16 : cfg == 2 ? MTMC_GEMM_INLOOP_128 : cfg == 1 ? MTMC_GEMM_INLOOP_64
                                                                                                            : MTMC_GEMM_GENERIC;
-    out->enc_split_k[l] = ((l == 0 && pre0) || stg || !slab) ? 1 : sk_here;
+    out->enc_split_k[l] = ((l == 0 && pre0) || stg || rws || !slab) ? 1 : sk_here;
   }
   out->edges_per_thread = mtmc::plan_edges_per_thread(c->n_edges);
   out->lazy_edges = lazy_edges(c) ? 1 : 0;
@@ -210,14 +211,17 @@ int32_t mtmc_linear_raw(const float* A, int64_t lda, const float* W, const float
   return e == hipSuccess ? MTMC_OK : fail(MTMC_E_HIP, "launch failed: %s", hipGetErrorString(e));
 }
 
-// Diagnostics / unit tests: one encoder layer >= 1 as the forward runs it on many-row graphs (gemm_staged.hip):
+// Diagnostics / unit tests: one encoder layer >= 1 as the forward runs it on many-row graphs:
 // Y[M][N] = relu(bn(A))[M][K] . W[N][K]^T + bias, bn = BatchNorm with the given column statistics (f64 sum[K] | sumsq[K] over
-// `count` rows) and gamma / beta.  work: >= 4*N*K + 4*N + 256 bytes (the weight planes); scratch: u32[48]; stats: f64[2*N] or NULL.
+// `count` rows) and gamma / beta -- on the role-split kernel (gemm_staged.hip: N % 256 == 0) or, for the narrow last layer
+// (K = 128, N = 32), the row-streaming kernel (gemm_rows.hip).  work: >= 4*N*K + 4*N + 256 bytes (the weight planes of the
+// role-split kernel); scratch: u32[48]; stats: f64[2*N] or NULL.
 int32_t mtmc_linear_staged_raw(const float* A, int64_t lda, const double* stats_in, const float* gamma_in, const float* beta_in,
                                double count, const float* W, const float* bias, float* Y, int64_t M, int32_t K, int32_t N,
                                void* work, uint64_t work_bytes, uint32_t* scratch, double* stats, void* stream) {
+  const bool narrow = K == 128 && N == 32;
   if (!A || !stats_in || !gamma_in || !beta_in || !W || !bias || !Y || !work || !scratch || M < 1 || K < 64 || K % 32 || K > 2048 ||
-      N < 256 || N % 256 || lda < K || (lda & 3) || ((uintptr_t)A & 15))
+      (!narrow && (N < 256 || N % 256)) || lda < K || (lda & 3) || ((uintptr_t)A & 15))
     return fail(MTMC_E_ARG, "bad arguments");
   const uint64_t iw_off = ((uint64_t)N * K * 4 + 255) / 256 * 256;
   if (work_bytes < iw_off + (uint64_t)N * 4) return fail(MTMC_E_ARG, "work buffer too small");
@@ -228,14 +232,25 @@ int32_t mtmc_linear_staged_raw(const float* A, int64_t lda, const double* stats_
   pp.n_edges = 0; pp.n_jobs = 1;
   pp.jobs[0] = {A, M, K, lda, scratch, 0, 0};
   mtmc::launch_prep(pp, s);
-  unsigned char* wk = static_cast<unsigned char*>(work);
-  mtmc::launch_split_rows(W, K, N, K, wk, reinterpret_cast<float*>(wk + iw_off), s);
-  mtmc::StagedGemmParams g;
-  g.A = A; g.lda = lda; g.stats_in = stats_in; g.gamma_in = gamma_in; g.beta_in = beta_in; g.count = count;
-  g.amax_a = scratch; g.Wh = reinterpret_cast<const _Float16*>(wk); g.inv_w = reinterpret_cast<const float*>(wk + iw_off);
-  g.bias = bias; g.Y = Y; g.ldy = N; g.stats_out = stats; g.amax_y = scratch + 2 * mtmc::kAmaxRep;
-  g.M = M; g.K = K; g.Nout = N;
-  const int rc = mtmc::launch_gemm_staged(g, s);
+  int rc;
+  if (narrow) {
+    mtmc::GemmParams g;
+    g.A = A; g.lda = lda; g.W = W; g.bias = bias; g.Y = Y; g.ldy = N;
+    g.stats_in = stats_in; g.gamma_in = gamma_in; g.beta_in = beta_in; g.count = count;
+    g.stats_out = stats; g.M = M; g.K = K; g.Nout = N;
+    g.slab = nullptr; g.split_k = 1; g.drop_in = {0, 0, 1.f, 0}; g.drop_stream = 0;
+    g.amax_a = scratch; g.amax_w = nullptr; g.amax_y = scratch + 2 * mtmc::kAmaxRep;
+    rc = mtmc::launch_gemm_rows(g, s);
+  } else {
+    unsigned char* wk = static_cast<unsigned char*>(work);
+    mtmc::launch_split_rows(W, K, N, K, wk, reinterpret_cast<float*>(wk + iw_off), s);
+    mtmc::StagedGemmParams g;
+    g.A = A; g.lda = lda; g.stats_in = stats_in; g.gamma_in = gamma_in; g.beta_in = beta_in; g.count = count;
+    g.amax_a = scratch; g.Wh = reinterpret_cast<const _Float16*>(wk); g.inv_w = reinterpret_cast<const float*>(wk + iw_off);
+    g.bias = bias; g.Y = Y; g.ldy = N; g.stats_out = stats; g.amax_y = scratch + 2 * mtmc::kAmaxRep;
+    g.M = M; g.K = K; g.Nout = N;
+    rc = mtmc::launch_gemm_staged(g, s);
+  }
   if (rc != 0) return fail(rc == MTMC_E_HIP ? MTMC_E_HIP : MTMC_E_ARG, "unsupported shape or launch refused");
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? MTMC_OK : fail(MTMC_E_HIP, "launch failed: %s", hipGetErrorString(e));

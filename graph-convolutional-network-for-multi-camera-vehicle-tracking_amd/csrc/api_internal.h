@@ -317,6 +317,12 @@ inline bool use_staged(const Ctx& x, int l) {
   return l >= 1 && x.lo.staged[l] && mtmc::staged_layer(x.c->node_hi - x.c->node_lo, x.m->enc_node[l].in_dim, x.m->enc_node[l].out_dim);
 }
 
+// layer l >= 1 on the row-streaming kernel (narrow last layers of many-row graphs, eval mode)
+inline bool use_rows(const Ctx& x, int l) {
+  return l >= 1 && !x.lo.training && mtmc::rows_layer(x.c->n_nodes, x.m->enc_node[l].in_dim, x.m->enc_node[l].out_dim) &&
+         mtmc::rows_layer(x.c->node_hi - x.c->node_lo, x.m->enc_node[l].in_dim, x.m->enc_node[l].out_dim);
+}
+
 enum { kPhMemset = -1, kPhPrep = -2 };   // the two halves of MTMC_PH_BEGIN, for the forked forward
 
 inline const int* scale_deg(const Ctx& x) {   // the degree mean aggregation divides by
@@ -348,7 +354,7 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
         if (c->node_hi > c->node_lo) {
           if (!pre0) p.jobs[p.n_jobs++] = {c->x, c->node_hi - c->node_lo, m->enc_node[0].in_dim, c->x_row_stride, amax, 0, 0};
           for (int l = pre0 ? 1 : 0; l < m->n_enc_layers; ++l)
-            if (!use_staged(x, l))              // (a staged layer's weights are split into planes below instead)
+            if (!use_staged(x, l) && !use_rows(x, l))   // (staged: weights split into planes below; row-streaming: in the kernel)
               p.jobs[p.n_jobs++] = {m->enc_node[l].weight, m->enc_node[l].out_dim, m->enc_node[l].in_dim,
                                     m->enc_node[l].in_dim, amax + (1 + l) * mtmc::kAmaxRep, 0, 0};
         }
@@ -424,6 +430,12 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
         g.amax_a = arg == 0 ? amax : amax + (1 + MTMC_MAX_ENC_LAYERS + (arg - 1)) * mtmc::kAmaxRep;
         g.amax_w = amax + (1 + arg) * mtmc::kAmaxRep;
         g.amax_y = amax + (1 + MTMC_MAX_ENC_LAYERS + arg) * mtmc::kAmaxRep;
+      }
+      if (use_rows(x, arg)) {
+        if (phase == MTMC_PH_NODE_COMBINE) break;                // never split along K
+        g.slab = nullptr; g.split_k = 1;
+        if (mtmc::launch_gemm_rows(g, s) != 0) return fail(MTMC_E_ARG, "encoder layer %d: row-streaming GEMM refused the shape", arg);
+        break;
       }
       {  // the slab was sized for N rows; a shard with fewer rows may plan a larger split
         int sk_full, sk_here;

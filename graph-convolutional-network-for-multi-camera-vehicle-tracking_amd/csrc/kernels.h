@@ -134,6 +134,9 @@ struct StagedGemmParams {
 };
 bool staged_layer(int64_t rows, int K, int Nout);       // many rows, K % 32 == 0, K <= 2048, Nout % 128 == 0, not disabled
 int launch_gemm_staged(const StagedGemmParams& p, hipStream_t s);   // 0 ok, 1 unsupported shape, MTMC_E_HIP
+// The last, narrow encoder layers of many-row graphs as a row-streaming kernel (gemm_rows.hip): 128 -> 32
+bool rows_layer(int64_t rows, int K, int Nout);
+int launch_gemm_rows(const GemmParams& p, hipStream_t s);          // 0 ok, 1 unsupported shape
 void launch_split_rows(const float* X, int64_t ld, int64_t rows, int K, void* H, float* inv, hipStream_t s);
 // hipFuncAttributeMaxDynamicSharedMemorySize, once per (kernel, device); false when HIP refuses (gemm_bn.hip)
 bool allow_big_lds(const void* fn, int bytes);

@@ -198,12 +198,13 @@ int32_t mtmc_mpn_run_phase(const mtmc_mpn_model* model, const mtmc_mpn_call* cal
  * sizes, ranges, flags and `training`), so that a multi-GPU host or a test can check that a SHARD takes the kernels the
  * whole graph would.  Encoder layers are planned for the node_hi - node_lo rows the call encodes. */
 enum { MTMC_GEMM_GENERIC = 0, MTMC_GEMM_INLOOP_64 = 1, MTMC_GEMM_INLOOP_128 = 2, MTMC_GEMM_PRESPLIT_256 = 3,
-       MTMC_GEMM_STAGED_128 = 4 };
+       MTMC_GEMM_STAGED_128 = 4, MTMC_GEMM_ROWS_16 = 5 };
 enum { MTMC_PASS_C_WALK = 0, MTMC_PASS_C_MFMA_SORTED = 1, MTMC_PASS_C_MFMA_ANY = 2 };
 typedef struct mtmc_mpn_plan {
   int32_t enc_kernel[MTMC_MAX_ENC_LAYERS];   /* MTMC_GEMM_*: one-thread-per-output fallback / in-loop operand split on
                                                 64x64 or 128x128 tiles / pre-split fp16 planes + 256x256 tiles / (layers
-                                                >= 1 of many-row graphs) 128-row tiles staged by producer waves      */
+                                                >= 1 of many-row graphs) 128-row tiles staged by producer waves /
+                                                (narrow last layers of many-row graphs) one wave per 16 rows         */
   int32_t enc_split_k[MTMC_MAX_ENC_LAYERS];  /* K slices (few-row layers; > 1 => MTMC_PH_NODE_COMBINE does work)    */
   int32_t edges_per_thread;                  /* passes A / B                                                        */
   int32_t lazy_edges;                        /* 1: e' is never stored, consumers recompute it from z1               */
@@ -237,10 +238,11 @@ int32_t mtmc_mlp_layer_forward(const mtmc_layer* layer, const float* x, int64_t 
 int32_t mtmc_linear_raw(const float* A, int64_t lda, const float* W, const float* bias, float* Y, int64_t M, int32_t K,
                         int32_t N, uint32_t* scratch, double* stats, void* stream);
 
-/* One encoder layer >= 1 as the forward runs it on graphs with >= 4096 nodes (csrc/gemm_staged.hip):
+/* One encoder layer >= 1 as the forward runs it on many-row graphs (csrc/gemm_staged.hip: role-split kernel, N a multiple
+ * of 256; csrc/gemm_rows.hip: row-streaming kernel for the narrow last layer, K = 128 and N = 32):
  * Y[M][N] = relu(bn(A))[M][K] . W[N][K]^T + bias, bn = BatchNorm1d with batch statistics given as stats_in = f64 column
  * sum[K] | sum of squares[K] over `count` rows, and gamma_in / beta_in [K] (reference models/mlp.py:14-27: the previous
- * group's BatchNorm + ReLU fused into this Linear).  K a multiple of 32 in [64, 2048], N a multiple of 256.
+ * group's BatchNorm + ReLU fused into this Linear).  K a multiple of 32 in [64, 2048].
  * work: >= 4*N*K + 4*N + 256 bytes; scratch: u32[48]; stats: f64[2*N] column sum / sum of squares of Y, or NULL. */
 int32_t mtmc_linear_staged_raw(const float* A, int64_t lda, const double* stats_in, const float* gamma_in,
                                const float* beta_in, double count, const float* W, const float* bias, float* Y, int64_t M,

@@ -1,4 +1,5 @@
-"""The role-split encoder GEMM (csrc/gemm_staged.hip, mtmc_linear_staged_raw): Y = relu(bn(A)) . W^T + b against float64 --
+"""The many-row encoder GEMMs behind mtmc_linear_staged_raw -- the role-split kernel (csrc/gemm_staged.hip, N % 256 == 0) and
+the row-streaming kernel for the narrow last layer (csrc/gemm_rows.hip, 128 -> 32): Y = relu(bn(A)) . W^T + b against float64 --
 ragged row counts (tile heights 80..128 are picked per launch), odd k-tile counts, strided A, columns whose
 BatchNorm kills or keeps everything, an outlier element.  Bound: 5e-7 * (sum_k |a||w| + |b|) plus
 the fp32 rounding of the BatchNorm affine itself (see _ref)."""
@@ -42,7 +43,8 @@ def _ref(A, st_in, gamma, beta, W, b, count, split=5e-7):
     return a, a @ W.double().t() + b.double(), bound
 
 
-@pytest.mark.parametrize("shape", [(128, 64, 256), (300, 96, 256), (1000, 512, 768), (777, 1024, 512), (4100, 2048, 256), (33000, 160, 256)])
+@pytest.mark.parametrize("shape", [(128, 64, 256), (300, 96, 256), (1000, 512, 768), (777, 1024, 512), (4100, 2048, 256), (33000, 160, 256),
+                                   (16, 128, 32), (1000, 128, 32), (70001, 128, 32)])
 def test_staged_matches_float64(shape):
     M, K, N = shape
     g = torch.Generator(device="cuda").manual_seed(M + 3 * N)

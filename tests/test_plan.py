@@ -25,7 +25,7 @@ N5, E5 = 1_000_000, 100_000_000          # BASELINE config 5
 def test_config5_shards_take_the_whole_graphs_kernels(eng, world):
     whole = eng.plan(N5, E5)
     assert whole.pass_c == _lib.PASS_C_MFMA_SORTED and whole.lazy_edges and whole.edges_per_thread == 4
-    assert whole.enc_kernel[:3] == [_lib.GEMM_PRESPLIT_256, _lib.GEMM_STAGED_128, _lib.GEMM_INLOOP_128]
+    assert whole.enc_kernel == [_lib.GEMM_PRESPLIT_256, _lib.GEMM_STAGED_128, _lib.GEMM_INLOOP_128, _lib.GEMM_ROWS_16]
     rows = mdist.even_ranges(N5, world)
     edges = mdist.even_ranges(E5, world)
     for r in range(world):
@@ -39,7 +39,7 @@ def test_config5_shards_take_the_whole_graphs_kernels(eng, world):
         for p in (own, gen):
             assert p.pass_c == whole.pass_c, f"rank {r}/{world} left the matrix-core pass C"
             assert p.lazy_edges == whole.lazy_edges and p.edges_per_thread == whole.edges_per_thread
-            assert p.enc_kernel[:3] == whole.enc_kernel[:3] and p.enc_split_k == whole.enc_split_k
+            assert p.enc_kernel == whole.enc_kernel and p.enc_split_k == whole.enc_split_k
 
 
 def test_row_complete_shard_is_judged_on_its_own_rows(eng):
