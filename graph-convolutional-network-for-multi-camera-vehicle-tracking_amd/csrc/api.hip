@@ -213,7 +213,7 @@ int32_t mtmc_linear_raw(const float* A, int64_t lda, const float* W, const float
 
 // Diagnostics / unit tests: one encoder layer >= 1 as the forward runs it on many-row graphs:
 // Y[M][N] = relu(bn(A))[M][K] . W[N][K]^T + bias, bn = BatchNorm with the given column statistics (f64 sum[K] | sumsq[K] over
-// `count` rows) and gamma / beta -- on the role-split kernel (gemm_staged.hip: N % 256 == 0) or, for the narrow last layer
+// `count` rows) and gamma / beta -- on the role-split kernel (gemm_staged.hip: N % 256 == 0, or N = 128) or, for the narrow last layer
 // (K = 128, N = 32), the row-streaming kernel (gemm_rows.hip).  work: >= 4*N*K + 4*N + 256 bytes (the weight planes of the
 // role-split kernel); scratch: u32[48]; stats: f64[2*N] or NULL.
 int32_t mtmc_linear_staged_raw(const float* A, int64_t lda, const double* stats_in, const float* gamma_in, const float* beta_in,
@@ -221,7 +221,7 @@ int32_t mtmc_linear_staged_raw(const float* A, int64_t lda, const double* stats_
                                void* work, uint64_t work_bytes, uint32_t* scratch, double* stats, void* stream) {
   const bool narrow = K == 128 && N == 32;
   if (!A || !stats_in || !gamma_in || !beta_in || !W || !bias || !Y || !work || !scratch || M < 1 || K < 64 || K % 32 || K > 2048 ||
-      (!narrow && (N < 256 || N % 256)) || lda < K || (lda & 3) || ((uintptr_t)A & 15))
+      (!narrow && N != 128 && (N < 256 || N % 256)) || lda < K || (lda & 3) || ((uintptr_t)A & 15))
     return fail(MTMC_E_ARG, "bad arguments");
   const uint64_t iw_off = ((uint64_t)N * K * 4 + 255) / 256 * 256;
   if (work_bytes < iw_off + (uint64_t)N * 4) return fail(MTMC_E_ARG, "work buffer too small");

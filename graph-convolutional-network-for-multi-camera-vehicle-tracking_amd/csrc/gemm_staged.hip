@@ -26,21 +26,31 @@
 
 namespace mtmc {
 
+#ifndef SG_ABL
+#define SG_ABL 0          // timing ablations (tools/staged_ablate.sh); results are garbage for any value but 0
+#endif
 
-constexpr int kSgBM = 128, kSgBK = 32, kSgRowB = kSgBK * 2;      // bytes per image row
-constexpr int kSgAImg = kSgBM * kSgRowB;                         // one A piece of one stage: 8 KB
+
+constexpr int kSgBK = 32, kSgRowB = kSgBK * 2;                   // bytes per image row
 constexpr int kSgNT = 768;                                       // 4 producer + 8 consumer waves: one + two per SIMD
 constexpr int kSgSets = 3;                                       // register sets of the producers: A is loaded two k-tiles ahead
 constexpr int kSgNW = 3;                                         // W stages: LDS-DMA runs two k-tiles ahead (a DMA takes
                                                                  // ~1 us from issue to landed under load, a k-tile less)
 
-template <int BN>
+// The eight consumer waves form WM x WN = 2 x 4 (tile up to 128 rows x 256 columns: the wide layers) or 4 x 2 (up to 256 x 128:
+// Nout = 128, where 256-column tiles do not exist and 128 x 128 ones left a wave 24 MFMAs per k-tile); either way a wave owns
+// 64 rows x 64 columns = 48 MFMAs per k-tile, and the waves wm and wm + WM/2 share a SIMD.
+template <int BN, int WM>
 __global__ __launch_bounds__(kSgNT) void gemm_staged_kernel(StagedGemmParams p, int tiles_m, int tiles_n, int bm) {
+  constexpr int WN = 8 / WM;                           // consumer waves across the tile's columns
+  constexpr int BM = 64 * WM;                          // rows of the A stages (the tile uses the first bm of them)
+  constexpr int NH = BM / 32;                          // rows per producer lane: 4 or 8
+  constexpr int AIMG = BM * kSgRowB;                   // one A piece of one stage
   constexpr int WIMG = BN * kSgRowB;                   // one W piece of one stage
-  constexpr int WC = BN / 4;                           // columns per consumer wave (2 x 4 waves, 64 rows x WC columns each)
-  constexpr int TJ = WC / 16;                          // 16-column blocks per consumer wave: 4 or 2
+  constexpr int WC = BN / WN;                          // columns per consumer wave: 64
+  constexpr int TJ = WC / 16;                          // 16-column blocks per consumer wave
   constexpr int WJ = BN / 128;                         // DMA instructions per W piece per consumer wave (128 rows per pass of the eight)
-  constexpr int WST = 2 * WIMG, AST = 2 * kSgAImg;     // one stage of W (piece 1, piece 2) / of A
+  constexpr int WST = 2 * WIMG, AST = 2 * AIMG;        // one stage of W (piece 1, piece 2) / of A
   constexpr int A0 = kSgNW * WST;                      // LDS: [kSgNW] W stages, then [2] A stages, then the input affine
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* s_in = reinterpret_cast<float*>(smem + A0 + 2 * AST);       // [K]
@@ -54,7 +64,8 @@ __global__ __launch_bounds__(kSgNT) void gemm_staged_kernel(StagedGemmParams p, 
   const int tm_idx = __builtin_amdgcn_readfirstlane((slot / tiles_n) * 8 + xcd);
   const int tn_idx = __builtin_amdgcn_readfirstlane(slot % tiles_n);
   if (tm_idx >= tiles_m) return;
-  const int64_t m0 = (int64_t)tm_idx * bm;             // bm: the tile's height, a multiple of 16 in [80, 128] (launch_gemm_staged)
+  const int64_t m0 = (int64_t)tm_idx * bm;             // bm: the tile's height (staged_tile_rows): the first WM/2 rows of consumer
+  const int xr = (bm - 32 * WM) / (WM / 2);            // waves take 64 rows each, the others xr (a multiple of 16, <= 64) each
   const int n0 = tn_idx * BN;
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool producer = wid < 4;
@@ -109,27 +120,36 @@ __global__ __launch_bounds__(kSgNT) void gemm_staged_kernel(StagedGemmParams p, 
     // Lane t takes the 16-byte chunk (t & 7) -- k = 4 * chunk .. + 3 of the k-tile -- of rows (t >> 3) + 32 h, h = 0..3:
     // a load instruction reads whole 128-byte lines, eight rows per wave.
     const int pt = threadIdx.x, c8 = pt & 7, r0 = pt >> 3;
-    const float* a_src[4];
-    unsigned a_dst[4];
+    const float* a_src[NH];
+    unsigned a_dst[NH];
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
+    for (int h = 0; h < NH; ++h) {
       const int r = r0 + 32 * h;
       const int64_t row = (r < bm && m0 + r < p.M) ? m0 + r : m0;    // rows past M or past the tile's height: the tile's
       a_src[h] = p.A + row * p.lda + c8 * 4;                         // first row again (cached; what they feed is never stored)
       a_dst[h] = (unsigned)(r * kSgRowB + (((c8 >> 1) ^ ((r >> 2) & 3)) << 4) + (c8 & 1) * 8);   // the fragment reads' swizzle
     }
-    float4 ra[kSgSets][4];                               // [register set][row]
+    float4 ra[kSgSets][NH];                              // [register set][row]
     auto load_a = [&](int kt, int set) {
 #pragma unroll
-      for (int h = 0; h < 4; ++h) ra[set][h] = *reinterpret_cast<const float4*>(a_src[h] + kt * kSgBK);
+      for (int h = 0; h < NH; ++h) {
+        if (SG_ABL == 2 || SG_ABL == 6) ra[set][h] = float4{(float)kt, 1.f, 2.f, (float)h};
+        else ra[set][h] = *reinterpret_cast<const float4*>(a_src[h] + kt * kSgBK);
+      }
     };
     auto convert_a = [&](int kt, int set) {
+      if (SG_ABL == 6) return;
       unsigned char* st = smem + A0 + (kt & 1) * AST;
       const float4 s4 = *reinterpret_cast<const float4*>(s_in + kt * kSgBK + c8 * 4);
       const float4 t4 = *reinterpret_cast<const float4*>(t_in + kt * kSgBK + c8 * 4);
 #pragma unroll
-      for (int h = 0; h < 4; ++h) {
+      for (int h = 0; h < NH; ++h) {
         const float4 v = ra[set][h];
+        if (SG_ABL == 1) {                                  // no conversion arithmetic: the loaded bits go straight to LDS
+          *reinterpret_cast<uint2*>(st + a_dst[h]) = uint2{__float_as_uint(v.x), __float_as_uint(v.y)};
+          *reinterpret_cast<uint2*>(st + AIMG + a_dst[h]) = uint2{__float_as_uint(v.z), __float_as_uint(v.w)};
+          continue;
+        }
         // relu(bn(y)) scaled into fp16's range, then h1 = rtz(x), h2 = rtz(x - h1) (exact residual; see gemm_bn.hip `put`)
         const float x0 = fmaxf(fmaf(v.x, s4.x, t4.x), 0.f) * sa, x1 = fmaxf(fmaf(v.y, s4.y, t4.y), 0.f) * sa;
         const float x2 = fmaxf(fmaf(v.z, s4.z, t4.z), 0.f) * sa, x3 = fmaxf(fmaf(v.w, s4.w, t4.w), 0.f) * sa;
@@ -140,7 +160,7 @@ __global__ __launch_bounds__(kSgNT) void gemm_staged_kernel(StagedGemmParams p, 
         q1.x = __builtin_bit_cast(unsigned, a01); q1.y = __builtin_bit_cast(unsigned, a23);
         q2.x = __builtin_bit_cast(unsigned, b01); q2.y = __builtin_bit_cast(unsigned, b23);
         *reinterpret_cast<uint2*>(st + a_dst[h]) = q1;
-        *reinterpret_cast<uint2*>(st + kSgAImg + a_dst[h]) = q2;
+        *reinterpret_cast<uint2*>(st + AIMG + a_dst[h]) = q2;
       }
     };
     // One k-tile of producer work.  A(k) lives in register set k % 3: tile kt+3 is loaded into set `ld` = kt % 3 (free:
@@ -171,7 +191,7 @@ __global__ __launch_bounds__(kSgNT) void gemm_staged_kernel(StagedGemmParams p, 
     // matrix pipe busy.  Thread t fills chunk (t & 3) of rows (t >> 2) + 128 j of both pieces: a uniform base (SGPRs,
     // advanced by SALU) + a loop-invariant lane offset.
     const int cw = wid - 4, ct = threadIdx.x - 256;
-    const int wm = cw >> 2, wn = cw & 3;
+    const int wm = cw / WN, wn = cw % WN;
     unsigned off_w[WJ];
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
@@ -184,6 +204,7 @@ __global__ __launch_bounds__(kSgNT) void gemm_staged_kernel(StagedGemmParams p, 
     const int64_t w_plane = (int64_t)p.Nout * p.K * 2, w_kt = (int64_t)p.Nout * kSgBK * 2;
     // one of the wave's 2 * WJ LDS-DMA instructions of k-tile kt (g = piece * WJ + pass)
     auto dma_one = [&](int kt, int g) {
+      if (SG_ABL == 4) return;
       const int q = g / WJ, j = g % WJ;
       lds_dma16(w_tile + q * w_plane + kt * w_kt, off_w[j], lds0 + (kt % kSgNW) * WST + cw * 1024 + q * WIMG + j * 8192);
     };
@@ -193,8 +214,9 @@ __global__ __launch_bounds__(kSgNT) void gemm_staged_kernel(StagedGemmParams p, 
     };
     const int r16 = lane & 15, ks = lane >> 4;                       // fragment row inside a 16-row block, 8-half k group
     const int so = (ks ^ ((r16 >> 2) & 3)) * 16;                     // the stored swizzle: slot ^ ((row >> 2) & 3)
-    const int a_row = (wm * 64 + r16) * kSgRowB + so, b_row = (wn * WC + r16) * kSgRowB + so;
-    const int nblk = wm == 0 ? 4 : (bm - 64) / 16;                   // 16-row blocks of this wave (tile height bm: 80..128)
+    const int wrow = wm < WM / 2 ? 64 * wm : 32 * WM + (wm - WM / 2) * xr;    // this wave's first row of the tile
+    const int a_row = (wrow + r16) * kSgRowB + so, b_row = (wn * WC + r16) * kSgRowB + so;
+    const int nblk = wm < WM / 2 ? 4 : xr / 16;                      // 16-row blocks of this wave
 
     dma_w(0);
     if (nk > 1) {
@@ -212,15 +234,32 @@ __global__ __launch_bounds__(kSgNT) void gemm_staged_kernel(StagedGemmParams p, 
 #pragma unroll
       for (int j = 0; j < TJ; ++j)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) b[j][q] = *reinterpret_cast<const f16x8*>(st + q * WIMG + b_row + j * 16 * kSgRowB);
+        for (int q = 0; q < 2; ++q) {
+          if (SG_ABL == 5) b[j][q] = f16x8{(_Float16)kt, 1, 2, 3, 4, 5, 6, (_Float16)j};
+          else b[j][q] = *reinterpret_cast<const f16x8*>(st + q * WIMG + b_row + j * 16 * kSgRowB);
+        }
+      // the A fragments of block i + 1 are read BEFORE block i's MFMAs (two register sets): read right before their use,
+      // every block began with an exposed LDS round trip
+      f16x8 af[2][2];
+      auto read_a = [&](int i, int set) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          if (SG_ABL == 5) af[set][q] = f16x8{(_Float16)kt, 1, 2, 3, 4, 5, 6, (_Float16)i};
+          else af[set][q] = *reinterpret_cast<const f16x8*>(as + q * AIMG + a_row + i * 16 * kSgRowB);
+        }
+      };
+      read_a(0, 0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        f16x8 a[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) a[q] = *reinterpret_cast<const f16x8*>(as + q * kSgAImg + a_row + i * 16 * kSgRowB);
+        if (i + 1 < 4) read_a(i + 1, (i + 1) & 1);
+        const f16x8* a = af[i & 1];
         if (i < nblk) {                                    // (rows past the tile's height: wave-uniform skip)
 #pragma unroll
           for (int j = 0; j < TJ; ++j) {                   // the three products of a block back to back (gemm_presplit.hip)
+            if (SG_ABL == 3) {                             // no matrix work: the fragments are only kept alive
+              asm volatile("" ::"v"(a[0]), "v"(a[1]), "v"(b[j][0]), "v"(b[j][1]));
+              continue;
+            }
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], b[j][0], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[j][0], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[j][1], acc[i][j], 0, 0, 0);
@@ -246,9 +285,9 @@ __global__ __launch_bounds__(kSgNT) void gemm_staged_kernel(StagedGemmParams p, 
   // ---- epilogue (consumers; the producers only join the barriers): undo the scales, bias, raw Y through a per-wave LDS
   // transposition (whole row segments of 4 * WC bytes, as gemm_f16p_m16_kernel), fp64 column statistics, |Y|max
   __syncthreads();
-  const int cw = (wid + 4) & 7, wm = cw >> 2, wn = cw & 3;            // (wid - 4 for the consumers)
+  const int cw = (wid + 4) & 7, wm = cw / WN, wn = cw % WN;           // (wid - 4 for the consumers)
   float* stg = reinterpret_cast<float*>(smem) + cw * (16 * WC);
-  double* colred = reinterpret_cast<double*>(smem + 8 * 16 * WC * sizeof(float));   // [2 (wm)][2 (sum, sq)][BN], behind the strips
+  double* colred = reinterpret_cast<double*>(smem + 8 * 16 * WC * sizeof(float));   // [WM][2 (sum, sq)][BN], behind the strips
   float ymax = 0.f;
   if (!producer) {
     const int r16 = lane & 15, ks = lane >> 4;
@@ -268,12 +307,13 @@ __global__ __launch_bounds__(kSgNT) void gemm_staged_kernel(StagedGemmParams p, 
     constexpr int RPI = 64 / LPR;                        // rows per store instruction: 4 or 8
     const int rrow = lane / LPR, rcol = (lane % LPR) * 4;
     const int gcol = n0 + wn * WC + rcol;
-    const int nblk = wm == 0 ? 4 : (bm - 64) / 16;
+    const int nblk = wm < WM / 2 ? 4 : xr / 16;
+    const int wrow = wm < WM / 2 ? 64 * wm : 32 * WM + (wm - WM / 2) * xr;
     const int64_t m_end = m0 + bm < p.M ? m0 + bm : p.M;             // rows of this tile: [m0, m_end)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i < nblk) {                                       // (wave-uniform; no `break`: the loop must unroll, acc[] is registers)
-      const int64_t row0 = m0 + wm * 64 + i * 16;
+      const int64_t row0 = m0 + wrow + i * 16;
 #pragma unroll
       for (int j = 0; j < TJ; ++j) {
         const bool cok = n0 + wn * WC + j * 16 + r16 < p.Nout;
@@ -330,8 +370,12 @@ __global__ __launch_bounds__(kSgNT) void gemm_staged_kernel(StagedGemmParams p, 
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * BN; i += kSgNT) {
     const int which = i / BN, cl = i % BN, col = n0 + cl;
-    if (col < p.Nout && p.stats_out)
-      unsafeAtomicAdd(p.stats_out + which * p.Nout + col, colred[(0 * 2 + which) * BN + cl] + colred[(1 * 2 + which) * BN + cl]);
+    if (col < p.Nout && p.stats_out) {
+      double v = 0;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) v += colred[(w * 2 + which) * BN + cl];
+      unsafeAtomicAdd(p.stats_out + which * p.Nout + col, v);
+    }
   }
   if (p.amax_y) {
 #pragma unroll
@@ -350,42 +394,57 @@ __global__ __launch_bounds__(kSgNT) void gemm_staged_kernel(StagedGemmParams p, 
 }
 
 // which layers: eval mode (no Dropout here), an input BatchNorm (layers >= 1), many rows (the plan of the in-loop kernel
-// would be 128 x 128 tiles), K a multiple of 32 whose affine fits beside the stages, Nout a multiple of 256.  (Narrower
-// layers stay on the in-loop kernel: with 128-column tiles a k-tile is 24 MFMAs per wave and the per-k-tile hand-off
-// dominates -- 100000 x 512 -> 128 measured 0.122 ms here against 0.094 ms in-loop.)
+// would be 128 x 128 tiles), K a multiple of 32 whose affine fits beside the stages, and
+//   Nout a multiple of 256: 128-row x 256-column tiles (consumers 2 x 4);
+//   Nout = 128 and enough rows to fill the chip with 256-row tiles: 256 x 128 (consumers 4 x 2).  (128 x 128 tiles with 2 x 4
+//   consumers -- 24 MFMAs per wave and k-tile -- measured 0.122 ms on 100000 x 512 -> 128 against 0.094 ms in-loop.)
+static int staged_wm(int64_t rows, int Nout) {           // rows of consumer waves: 2, 4, or 0 = not a role-split layer
+  if (Nout >= 256 && Nout % 256 == 0) return rows >= 4096 ? 2 : 0;
+  if (Nout == 128) return rows >= 49152 ? 4 : 0;
+  return 0;
+}
+
 bool staged_layer(int64_t rows, int K, int Nout) {
   const Knobs& kn = knobs();
   if (kn.gemm_no_staged || kn.gemm_fp32 || kn.gemm_no_f16) return false;
   int sk;
-  return rows >= 4096 && K % 32 == 0 && K >= 64 && K <= 2048 && Nout >= 256 && Nout % 256 == 0 && gemm_plan(rows, K, Nout, &sk) == 2;
+  return staged_wm(rows, Nout) != 0 && K % 32 == 0 && K >= 64 && K <= 2048 && gemm_plan(rows, K, Nout, &sk) == 2;
 }
 
 // Tile height: with M / 128 x Nout / BN tiles on 256 CUs the last round of workgroups can be nearly empty (config 4, layer 1:
-// 1564 tiles = 6.1 rounds, paid as 7).  The height is a launch parameter (a multiple of 16 in [80, 128]; the second row of
-// consumer waves takes bm - 64 rows, and the two waves that share a SIMD always add up to bm): take the one that minimises
-// rounds x height -- 112 rows there: 1786 tiles = 6.98 rounds of 7/8 of the work each.
-int staged_tile_rows(int64_t M, int tiles_n) {
-  int best = kSgBM;
+// 1564 tiles = 6.1 rounds, paid as 7).  The height is a launch parameter: the first wm/2 rows of consumer waves take 64 rows
+// each, the others xr each (a multiple of 16 up to 64), and the two waves that share a SIMD always add up to 64 + xr -- heights
+// 80..128 step 16 for wm = 2, 160..256 step 32 for wm = 4.  Take the one that minimises rounds x height: 112 rows for that
+// layer 1 (1786 tiles = 6.98 rounds of 7/8 of the work each), 224 for its layer 2 (447 tiles, two rounds).
+int staged_tile_rows(int64_t M, int tiles_n, int wm) {
+  int best = 64 * wm;
   int64_t best_cost = -1;
-  for (int bm = kSgBM; bm >= 80; bm -= 16) {
+  for (int xr = 64; xr >= 16; xr -= 16) {
+    const int bm = 32 * wm + (wm / 2) * xr;
     const int64_t tiles = (M + bm - 1) / bm * tiles_n, rounds = (tiles + 255) / 256;
-    const int64_t cost = rounds * (bm + 8);              // + 8: a tile's fixed cost (prologue, epilogue) in row equivalents
+    const int64_t cost = rounds * (bm + 4 * wm);         // + 4 wm: a tile's fixed cost (prologue, epilogue) in row equivalents
     if (best_cost < 0 || cost < best_cost) { best = bm; best_cost = cost; }
   }
   return best;
 }
 
-int launch_gemm_staged(const StagedGemmParams& p, hipStream_t s) {
-  constexpr int bn = 256;
-  if (p.M < 1 || p.K % 32 || p.K < 64 || p.K > 2048 || p.Nout % bn || !p.stats_in || !p.amax_a) return 1;
-  const int tiles_n = p.Nout / bn;
-  const int bm = staged_tile_rows(p.M, tiles_n);
+template <int BN, int WM>
+static int launch_staged(const StagedGemmParams& p, hipStream_t s) {
+  const int tiles_n = p.Nout / BN;
+  const int bm = staged_tile_rows(p.M, tiles_n, WM);
   const int tiles_m = (int)((p.M + bm - 1) / bm);
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
-  const size_t lds = (size_t)kSgNW * 2 * bn * kSgRowB + (size_t)2 * 2 * kSgAImg + (size_t)(2 * p.K + 4 + 24) * sizeof(float);
-  if (!allow_big_lds(reinterpret_cast<const void*>(gemm_staged_kernel<bn>), 160 * 1024)) return MTMC_E_HIP;
-  hipLaunchKernelGGL(gemm_staged_kernel<bn>, dim3(grid), dim3(kSgNT), lds, s, p, tiles_m, tiles_n, bm);
+  const size_t lds = (size_t)kSgNW * 2 * BN * kSgRowB + (size_t)2 * 2 * (64 * WM) * kSgRowB + (size_t)(2 * p.K + 4 + 24) * sizeof(float);
+  if (!allow_big_lds(reinterpret_cast<const void*>(gemm_staged_kernel<BN, WM>), 160 * 1024)) return MTMC_E_HIP;
+  hipLaunchKernelGGL((gemm_staged_kernel<BN, WM>), dim3(grid), dim3(kSgNT), lds, s, p, tiles_m, tiles_n, bm);
   return MTMC_OK;
+}
+
+int launch_gemm_staged(const StagedGemmParams& p, hipStream_t s) {
+  if (p.M < 1 || p.K % 32 || p.K < 64 || p.K > 2048 || !p.stats_in || !p.amax_a) return 1;
+  if (p.Nout >= 256 && p.Nout % 256 == 0) return launch_staged<256, 2>(p, s);
+  if (p.Nout == 128) return launch_staged<128, 4>(p, s);
+  return 1;
 }
 
 }  // namespace mtmc

@@ -132,7 +132,7 @@ struct StagedGemmParams {
   unsigned* amax_y;                         // u32[kAmaxRep] (atomicMax) or nullptr
   int64_t M; int K; int Nout;
 };
-bool staged_layer(int64_t rows, int K, int Nout);       // many rows, K % 32 == 0, K <= 2048, Nout % 128 == 0, not disabled
+bool staged_layer(int64_t rows, int K, int Nout);       // many rows, K % 32 == 0, K <= 2048, Nout % 256 == 0 or (Nout == 128, rows >= 49152), not disabled
 int launch_gemm_staged(const StagedGemmParams& p, hipStream_t s);   // 0 ok, 1 unsupported shape, MTMC_E_HIP
 // The last, narrow encoder layers of many-row graphs as a row-streaming kernel (gemm_rows.hip): 128 -> 32
 bool rows_layer(int64_t rows, int K, int Nout);

@@ -203,7 +203,7 @@ enum { MTMC_PASS_C_WALK = 0, MTMC_PASS_C_MFMA_SORTED = 1, MTMC_PASS_C_MFMA_ANY =
 typedef struct mtmc_mpn_plan {
   int32_t enc_kernel[MTMC_MAX_ENC_LAYERS];   /* MTMC_GEMM_*: one-thread-per-output fallback / in-loop operand split on
                                                 64x64 or 128x128 tiles / pre-split fp16 planes + 256x256 tiles / (layers
-                                                >= 1 of many-row graphs) 128-row tiles staged by producer waves /
+                                                >= 1 of many-row graphs) 128 x 256 or 256 x 128 tiles staged by producer waves /
                                                 (narrow last layers of many-row graphs) one wave per 16 rows         */
   int32_t enc_split_k[MTMC_MAX_ENC_LAYERS];  /* K slices (few-row layers; > 1 => MTMC_PH_NODE_COMBINE does work)    */
   int32_t edges_per_thread;                  /* passes A / B                                                        */
@@ -239,7 +239,7 @@ int32_t mtmc_linear_raw(const float* A, int64_t lda, const float* W, const float
                         int32_t N, uint32_t* scratch, double* stats, void* stream);
 
 /* One encoder layer >= 1 as the forward runs it on many-row graphs (csrc/gemm_staged.hip: role-split kernel, N a multiple
- * of 256; csrc/gemm_rows.hip: row-streaming kernel for the narrow last layer, K = 128 and N = 32):
+ * of 256 or N = 128; csrc/gemm_rows.hip: row-streaming kernel for the narrow last layer, K = 128 and N = 32):
  * Y[M][N] = relu(bn(A))[M][K] . W[N][K]^T + bias, bn = BatchNorm1d with batch statistics given as stats_in = f64 column
  * sum[K] | sum of squares[K] over `count` rows, and gamma_in / beta_in [K] (reference models/mlp.py:14-27: the previous
  * group's BatchNorm + ReLU fused into this Linear).  K a multiple of 32 in [64, 2048].

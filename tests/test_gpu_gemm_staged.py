@@ -44,7 +44,9 @@ def _ref(A, st_in, gamma, beta, W, b, count, split=5e-7):
 
 
 @pytest.mark.parametrize("shape", [(128, 64, 256), (300, 96, 256), (1000, 512, 768), (777, 1024, 512), (4100, 2048, 256), (33000, 160, 256),
-                                   (16, 128, 32), (1000, 128, 32), (70001, 128, 32)])
+                                   (16, 128, 32), (1000, 128, 32), (70001, 128, 32),
+                                   (100, 64, 128), (1000, 512, 128), (2049, 96, 128), (50001, 512, 128),
+                                   (70000, 64, 128), (100000, 64, 128)])     # tile heights 160 and 224 (staged_tile_rows)
 def test_staged_matches_float64(shape):
     M, K, N = shape
     g = torch.Generator(device="cuda").manual_seed(M + 3 * N)
@@ -107,5 +109,5 @@ def test_staged_rejects_bad_shapes():
              torch.zeros(256, device="cuda"))                                   # K % 32 != 0
     A = torch.randn(200, 128, device="cuda")
     with pytest.raises(RuntimeError):
-        _run(A, torch.ones(128, device="cuda"), torch.zeros(128, device="cuda"), torch.randn(128, 128, device="cuda"),
-             torch.zeros(128, device="cuda"))                                   # N % 256 != 0
+        _run(A, torch.ones(128, device="cuda"), torch.zeros(128, device="cuda"), torch.randn(192, 128, device="cuda"),
+             torch.zeros(192, device="cuda"))                                   # N neither a multiple of 256 nor 128

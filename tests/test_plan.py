@@ -25,7 +25,7 @@ N5, E5 = 1_000_000, 100_000_000          # BASELINE config 5
 def test_config5_shards_take_the_whole_graphs_kernels(eng, world):
     whole = eng.plan(N5, E5)
     assert whole.pass_c == _lib.PASS_C_MFMA_SORTED and whole.lazy_edges and whole.edges_per_thread == 4
-    assert whole.enc_kernel == [_lib.GEMM_PRESPLIT_256, _lib.GEMM_STAGED_128, _lib.GEMM_INLOOP_128, _lib.GEMM_ROWS_16]
+    assert whole.enc_kernel == [_lib.GEMM_PRESPLIT_256, _lib.GEMM_STAGED_128, _lib.GEMM_STAGED_128, _lib.GEMM_ROWS_16]
     rows = mdist.even_ranges(N5, world)
     edges = mdist.even_ranges(E5, world)
     for r in range(world):
