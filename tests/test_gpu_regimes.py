@@ -158,7 +158,8 @@ def test_max_aggregation_and_reattach_at_tracker_scale(tracker):
 
 
 # ---- both sides of every dispatch threshold -----------------------------------------------------------------------------
-# The library switches kernels at: 4096 node rows (pre-split layer 0 vs the in-loop kernel; 8192: role-split layer 1), 524 288
+# The library switches kernels at: 4096 node rows (pre-split layer 0, role-split layer 1, row-streaming layer 3 vs the in-loop
+# kernel), 49 152 node rows (role-split layer 2 with 256-row tiles), 524 288
 # edges (edges per thread, lazy e', which pass-C combination), 32 768 edges and 24 edges per source row (matrix-core pass C
 # or the walk).  A graph just below and just above each of them must give the oracle's answer, and the plan query must
 # say the two sides really take different kernels (otherwise the test tests nothing).
@@ -171,6 +172,7 @@ def _random_sorted_graph(n, pairs, seed):
 THRESHOLDS = [
     # (name, graph below, graph above, plan attribute that must differ)
     ("4096 node rows", (4000, 60_000), (4200, 60_000), "enc_kernel"),
+    ("49152 node rows", (49_000, 150_000), (49_300, 150_000), "enc_kernel"),
     ("524288 edges", (3000, 255_000), (3000, 270_000), "edges_per_thread"),
     ("32768 edges", (500, 15_000), (500, 18_000), "pass_c"),
     ("24 edges per source row", (2000, 22_000), (2000, 26_000), "pass_c"),
