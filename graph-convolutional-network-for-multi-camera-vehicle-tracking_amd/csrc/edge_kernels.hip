@@ -474,9 +474,17 @@ __global__ __launch_bounds__(kTileC) void pass_c_kernel(RoundParams p) {
   __shared__ double st[10 + 64];           // e' second moments (10) | z2 sums (32) | z2 sums of squares (32)
   const int k = threadIdx.x & 31;          // channel
   const int hw = threadIdx.x >> 5;         // half-wave
-  if (p.mfma_c == 1 && p.flags[0] == 0) return; // row-sorted list: pass_c_mfma_kernel, launched just before, did this round
+  // many-edge row-sorted list: pass_c_sorted_kernel, launched just before, did every whole 64-edge chunk; what is left for
+  // this kernel are the < 64 edges behind the last one
+  int64_t e_first = 0;
+  if (p.mfma_c == 1 && p.flags[0] == 0) return;  // (MTMC_PASS_C_GENERAL: pass_c_mfma_kernel did all of a sorted list)
+  if (p.mfma_c == 3 && p.flags[0] == 0) {
+    e_first = p.n_edges & ~(int64_t)63;
+    if (e_first == p.n_edges) return;
+  }
   const int64_t n_tiles = (p.n_edges + kTileC - 1) / kTileC;
-  int64_t tile = blockIdx.x;
+  int64_t tile = e_first / kTileC + blockIdx.x;
+  if (tile >= n_tiles) return;
   // a tile's operands do not depend on the statistics: fetch the first one before waiting for those
   float4 ev;
   int rw;
@@ -523,7 +531,7 @@ __global__ __launch_bounds__(kTileC) void pass_c_kernel(RoundParams p) {
     }
     if (e < p.n_edges) {
       tile_row[threadIdx.x] = rw;
-      if (p.logits) {                                         // classifier on this edge (mpn.py:291-292)
+      if (p.logits && e >= e_first) {                         // classifier on this edge (mpn.py:291-292)
         float lg[MTMC_MAX_CLASSES];
         for (int c = 0; c < p.n_classes; ++c) {
           const float* w = p.cls_w + c * 4;
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(kTileC) void pass_c_kernel(RoundParams p) {
     }
     tile_e[threadIdx.x] = ev;
     __syncthreads();
-    const int n_here = (int)min((int64_t)32, p.n_edges - (base + hw * 32));   // may be <= 0
+    const int n_here = base + hw * 32 < e_first ? 0 : (int)min((int64_t)32, p.n_edges - (base + hw * 32));   // may be <= 0
     const int64_t chunk = (base >> 5) + hw;
     int cur = -1;
     bool first = true;
@@ -850,6 +858,248 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// pass C for MANY-edge ROW-SORTED lists (plan 1): the kernel above with everything a sorted list of whole 64-edge chunks
+// makes unnecessary taken out of the loop -- counters of round 3 (r03: SQ_INSTS_*) showed that kernel bound by instruction
+// issue, 189 vector + 142 scalar instructions per chunk, most of them bookkeeping:
+//  * only WHOLE chunks here (the < 64 edges behind the last whole chunk go to pass_c_kernel, launched behind this one):
+//    no clamped 64-bit addresses, no validity masks, a chunk's first / last rows are v_readlane of fixed lanes;
+//  * sorted rows: a group's first row is its lane 0, its last row its lane 31, and the group is covered by those two iff
+//    ballot(row == first) | ballot(row == last) is everything -- no search for "the first other edge";
+//  * the row constants c0 = s_k (Q[row][k] + b_k) + t_k ride in as the B operand of a K step whose A operand is the
+//    membership in the group's first (kk = 0) / last (kk = 1) row: lanes 0-31 of a B operand hold kk = 0, lanes 32-63 kk = 1,
+//    so ONE Q lookup per group -- row = lane < 32 ? first : last -- is that operand; no per-row lookups, no selects;
+//  * a two-row group's first share: its edges are a PREFIX of the group, register i of a lane holds edge (i&3) + 8(i>>2) +
+//    4 hi, so whole 4-register blocks lie on one side and only block n_first >> 3 is cut: block sums (needed for the total
+//    anyway) + four compares in the one cut block, instead of sixteen scalar-built lane masks;
+//  * the three-deep pipeline is unrolled by three with the stage registers renamed: no register moves.
+// Groups that touch three or more rows (low-degree stretches) take the masked pass per distinct row, as above.
+// ------------------------------------------------------------------------------------------------
+template <bool LAZY>
+__global__ __launch_bounds__(256) void pass_c_sorted_kernel(RoundParams p, int span_c) {
+  __shared__ double st[10 + 64];
+  __shared__ double st1[8];
+  __shared__ float s1s[4], t1s[4];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int k = lane & 31, hi = lane >> 5;
+  if (p.flags[0] != 0) return;                                // unsorted rows: pass_c_kernel does this round (block-uniform)
+  stat_gather2(p.stats + kRoundMOff + 4, 10, kMStride, p.stats + kRoundZ2Off, 64, kZ2Stride, st);
+  if (LAZY) stat_gather(p.stats + kRoundZ1Off, 8, kZ1Stride, st1);
+  __syncthreads();
+  float s1[4] = {1.f, 1.f, 1.f, 1.f}, t1[4] = {0.f, 0.f, 0.f, 0.f};
+  if (LAZY) {                                                 // the edge buffer holds z1: e' = relu(s1 z1 + t1), recomputed here
+    if (threadIdx.x < 4)
+      bn_affine(st1[threadIdx.x], st1[4 + threadIdx.x], p.e_total, p.ue_g[threadIdx.x], p.ue_bt[threadIdx.x],
+                s1s[threadIdx.x], t1s[threadIdx.x]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s1[j] = s1s[j]; t1[j] = t1s[j]; }
+  }
+  float sk, tk;
+  {
+    const float* a = p.un_w + k * p.un_ld + p.un_eoff;
+    const double quad = quad_form(a, 4, st);
+    bn_affine(st[10 + k], st[10 + 32 + k] + quad, p.e_total, p.un_g[k], p.un_bt[k], sk, tk);
+  }
+  const float b0 = sk * p.un_w[k * p.un_ld + p.un_eoff + hi];          // B[kk = hi][j = k] of the two K = 2 steps
+  const float b1 = sk * p.un_w[k * p.un_ld + p.un_eoff + 2 + hi];
+  const float cb = fmaf(sk, p.un_b[k], tk);
+  const bool two_class = p.logits != nullptr && p.n_classes == 2;
+  float cw[2][4] = {}, cbias[2] = {};
+  if (two_class)
+    for (int c = 0; c < 2; ++c) {
+      cbias[c] = p.cls_b[c];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cw[c][j] = p.cls_w[c * 4 + j];
+    }
+  const int lim_hi = 4 * hi;
+  const unsigned koff = (unsigned)k * 4u;
+
+  const int n_full = (int)(p.n_edges >> 6);                  // whole chunks (launch_pass_c: fewer than 2^31 of them)
+  const int n_spans = (n_full + span_c - 1) / span_c;
+  const int wave_stride = (int)gridDim.x * 4;
+  for (int span = (int)blockIdx.x * 4 + wid; span < n_spans; span += wave_stride) {
+    int cur = -1;                 // wave-uniform: the row whose partial sum `run` holds (this lane's channel, this half's edges)
+    float run = 0.f;
+    auto flush = [&]() {
+      if (cur >= 0) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(run), __float_as_uint(run), false, false);
+        const float tot = run + __uint_as_float(hi == 0 ? sw[1] : sw[0]);
+        if (hi == 0) unsafeAtomicAdd(p.h_acc + (int64_t)cur * kH + k, tot);
+      }
+    };
+    auto account = [&](int r, float part) {                     // add a group's partial sum to row r's run
+      if (r != cur) {
+        flush();
+        cur = r;
+        run = 0.f;
+      }
+      run += part;
+    };
+    const int c_beg = span * span_c, c_end = min(n_full, c_beg + span_c);
+    // stage registers: chunk c lives in slot c % 3 (literal at every use after inlining)
+    float4 ev[3];
+    int rw[3];
+    float qv[3][2];              // per group: Q[lane < 32 ? first row : last row][k]
+    int rows[3][4];              // first / last row of group 0, of group 1 (scalar)
+    auto fetch = [&](int c, int slot) {                         // whole chunks only: c is clamped to the last one
+      const int cc = min(c, n_full - 1);
+      const int64_t e0 = (int64_t)cc * 64;
+      ev[slot] = reinterpret_cast<const float4*>(p.e_out + e0 * 4)[lane];
+      rw[slot] = (p.row32 + e0)[lane];
+    };
+    auto lookup = [&](int slot) {                               // the chunk's row ids have landed: its four rows, its Q operands
+      rows[slot][0] = __builtin_amdgcn_readlane(rw[slot], 0);
+      rows[slot][1] = __builtin_amdgcn_readlane(rw[slot], 31);
+      rows[slot][2] = __builtin_amdgcn_readlane(rw[slot], 32);
+      rows[slot][3] = __builtin_amdgcn_readlane(rw[slot], 63);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int r = hi ? rows[slot][2 * g + 1] : rows[slot][2 * g];
+        // (uniform base + 32-bit byte offset: one shift-add per lookup instead of 64-bit address arithmetic;
+        // launch_pass_c takes this kernel only while N * 128 fits 32 bits)
+        qv[slot][g] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.Q) + (((unsigned)r << 7) + koff));
+      }
+    };
+    // one chunk: everything of slot sl0 is in registers; slot sl1's row ids have landed; slot sl2 is requested
+    auto step = [&](int c, int sl0, int sl1, int sl2) {
+      fetch(c + 2, sl2);
+      lookup(sl1);
+      float4 e4 = ev[sl0];
+      if (LAZY) {
+        e4.x = fmaxf(fmaf(e4.x, s1[0], t1[0]), 0.f); e4.y = fmaxf(fmaf(e4.y, s1[1], t1[1]), 0.f);
+        e4.z = fmaxf(fmaf(e4.z, s1[2], t1[2]), 0.f); e4.w = fmaxf(fmaf(e4.w, s1[3], t1[3]), 0.f);
+      }
+      const int rwc = rw[sl0];
+      if (p.logits != nullptr) {                               // classifier on this edge (mpn.py:291-292)
+        if (two_class) {
+          // two scalar FMA chains, kept apart: paired up by the SLP vectoriser they become v_pk_fma_f32 with op_sel,
+          // the form tools/check_isa.py bans from kernels with MFMAs
+          float lg0 = fmaf(cw[0][3], e4.w, fmaf(cw[0][2], e4.z, fmaf(cw[0][1], e4.y, fmaf(cw[0][0], e4.x, cbias[0]))));
+          asm volatile("" : "+v"(lg0));
+          const float lg1 = fmaf(cw[1][3], e4.w, fmaf(cw[1][2], e4.z, fmaf(cw[1][1], e4.y, fmaf(cw[1][0], e4.x, cbias[1]))));
+          reinterpret_cast<float2*>(p.logits + (int64_t)c * 128)[lane] = make_float2(lg0, lg1);
+        } else {
+          const int64_t e = (int64_t)c * 64 + lane;
+          for (int cc = 0; cc < p.n_classes; ++cc) {
+            const float* w = p.cls_w + cc * 4;
+            p.logits[e * p.n_classes + cc] = fmaf(w[3], e4.w, fmaf(w[2], e4.z, fmaf(w[1], e4.y, fmaf(w[0], e4.x, p.cls_b[cc]))));
+          }
+        }
+      }
+      // A operands: lanes 0..31 carry component k = 0 (2), lanes 32..63 component k = 1 (3) of edge (lane & 31)
+      const auto xy = __builtin_amdgcn_permlane32_swap(__float_as_uint(e4.x), __float_as_uint(e4.y), false, false);
+      const auto zw = __builtin_amdgcn_permlane32_swap(__float_as_uint(e4.z), __float_as_uint(e4.w), false, false);
+      // membership of the chunk's edges in each group's first / last row (sorted: a prefix / a suffix of the group)
+      const int ra0 = rows[sl0][0], rb0 = rows[sl0][1], ra1 = rows[sl0][2], rb1 = rows[sl0][3];
+      const unsigned ma0 = (unsigned)__ballot(rwc == ra0);
+      const unsigned mb0 = ra0 == rb0 ? 0u : (unsigned)__ballot(rwc == rb0);
+      const unsigned ma1 = (unsigned)(__ballot(rwc == ra1) >> 32);
+      const unsigned mb1 = ra1 == rb1 ? 0u : (unsigned)(__ballot(rwc == rb1) >> 32);
+      const unsigned ma[2] = {ma0, ma1}, mb[2] = {mb0, mb1};
+      const int ra[2] = {ra0, ra1}, rb[2] = {rb0, rb1};
+      if ((ma0 | mb0) == 0xffffffffu && (ma1 | mb1) == 0xffffffffu) {
+        f32x16c acc[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const unsigned long long member = (unsigned long long)ma[g] | ((unsigned long long)mb[g] << 32);
+          const float a_c = __builtin_amdgcn_inverse_ballot_w64(member) ? 1.0f : 0.0f;
+          f32x16c z = {};
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c, fmaf(sk, qv[sl0][g], cb), z, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(xy[g]), b0, acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(zw[g]), b1, acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          // relu as a signed-integer max (exact for every float, no canonicalising v_max_f32 x, x, x in front); sums per
+          // block of four registers = four consecutive edges of this half
+          float t[16], bs[4];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) t[i] = __int_as_float(max(__float_as_int(acc[g][i]), 0));
+#pragma unroll
+          for (int b = 0; b < 4; ++b) bs[b] = (t[4 * b] + t[4 * b + 1]) + (t[4 * b + 2] + t[4 * b + 3]);
+          const float total = (bs[0] + bs[1]) + (bs[2] + bs[3]);
+          if (mb[g] == 0u) {
+            account(ra[g], total);
+          } else {
+            const int n_a = __builtin_popcount(ma[g]);          // 1..31 edges of the first row: a prefix
+            const int q = n_a >> 3;                             // the block the boundary cuts (for one of the halves)
+            const int lim = (n_a & 7) - lim_hi;                 // its registers j < lim belong to the first row
+            float sa;
+            auto cut = [&](int b) {
+              const float c0 = 0 < lim ? t[4 * b] : 0.f, c1 = 1 < lim ? t[4 * b + 1] : 0.f;
+              const float c2 = 2 < lim ? t[4 * b + 2] : 0.f, c3 = 3 < lim ? t[4 * b + 3] : 0.f;
+              return (c0 + c1) + (c2 + c3);
+            };
+            if (q == 0) sa = cut(0);
+            else if (q == 1) sa = bs[0] + cut(1);
+            else if (q == 2) sa = (bs[0] + bs[1]) + cut(2);
+            else sa = (bs[0] + bs[1]) + (bs[2] + cut(3));
+            account(ra[g], sa);
+            account(rb[g], total - sa);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          f32x16c acc = {};
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(xy[g]), b0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(zw[g]), b1, acc, 0, 0, 0);
+          // three or more rows in the group: one masked pass per distinct row (up to four), else every register goes to
+          // its own row with one atomic (bounded cost, no run bookkeeping)
+          int n_rows = 0;
+          {
+            unsigned left = 0xffffffffu;
+            while (left != 0 && n_rows <= 4) {
+              const int r = __builtin_amdgcn_readfirstlane(__shfl(rwc, 32 * g + __ffs(left) - 1, 64));
+              left &= ~((unsigned)(__ballot(rwc == r) >> (32 * g)));
+              ++n_rows;
+            }
+          }
+          if (n_rows > 4) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int off = (i & 3) + 8 * (i >> 2) + 4 * hi;
+              const int r = __shfl(rwc, 32 * g + off, 64);
+              const float c0 = fmaf(sk, p.Q[(int64_t)r * kH + k], cb);
+              unsafeAtomicAdd(p.h_acc + (int64_t)r * kH + k, fmaxf(acc[i] + c0, 0.f));
+            }
+            continue;
+          }
+          unsigned done = 0;
+          while (done != 0xffffffffu) {
+            const int pos = __ffs(~done) - 1;
+            const int r = __builtin_amdgcn_readfirstlane(__shfl(rwc, 32 * g + pos, 64));
+            const unsigned same = (unsigned)(__ballot(rwc == r) >> (32 * g)) & ~done;
+            done |= same;
+            const float c0 = fmaf(sk, p.Q[(int64_t)r * kH + k], cb);
+            const unsigned mine = same >> (4 * hi);             // bit (i&3) + 8(i>>2): register i's edge of this half-wave
+            float sacc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const float tt = fmaxf(acc[i] + c0, 0.f);
+              sacc += ((mine >> ((i & 3) + 8 * (i >> 2))) & 1u) ? tt : 0.f;
+            }
+            account(r, sacc);
+          }
+        }
+      }
+    };
+    fetch(c_beg, 0);
+    fetch(c_beg + 1, 1);
+    lookup(0);
+    for (int c = c_beg; c < c_end; c += 3) {
+      step(c, 0, 1, 2);
+      if (c + 1 < c_end) step(c + 1, 1, 2, 0);
+      if (c + 2 < c_end) step(c + 2, 2, 0, 1);
+    }
+    flush();
+  }
+}
+
 __global__ __launch_bounds__(256) void classify_e0_kernel(EdgeEncParams enc, const float* attr, int64_t n_edges,
                                                           double e_total, const float* cls_w, const float* cls_b,
                                                           int n_classes, float* logits) {
@@ -948,15 +1198,29 @@ int plan_edges_per_thread(int64_t n_edges) { return pick_ept(n_edges); }
 void launch_pass_c(const RoundParams& p0, hipStream_t s) {
   RoundParams p = p0;
   p.mfma_c = plan_pass_c(p.agg, p.det != 0, p.drop_n.on != 0, p.n_edges, p.avg_degree);
-  if (p.mfma_c) {
-    // many edges: a resident grid (the block prologue -- 74 replicated statistics, one BatchNorm affine per channel -- is
-    // paid once per block, so blocks live long) whose waves take short spans round-robin (~6 spans per wave at config 4;
-    // 768 / 1024 / 1536 / 2048 blocks: 114 / 138 / 120 / 122 us per launch there -- the grid that is exactly resident wins);
-    // few edges: one 64-edge chunk per wave, as many waves as there are chunks
-    const int span_env = knobs().pass_c_span, max_blocks = knobs().pass_c_blocks;
+  const int span_env = knobs().pass_c_span, max_blocks = knobs().pass_c_blocks;
+  if (p.mfma_c == 1 && !knobs().pass_c_general && p.n_nodes < (1ll << 24)) {
+    // many-edge sorted lists: a grid of twice what is resident (104 registers: four blocks per CU; the block prologue -- 74 replicated
+    // statistics, one BatchNorm affine per channel -- is paid once per block) whose waves all take the same number of
+    // equally long spans: the span length is chosen so that spans = waves x m for the smallest m that keeps a span at
+    // <= 48 chunks (a span pays one pipeline fill; a wave that gets one span more than the others sets the kernel's time:
+    // at config 4, 8-chunk spans round-robin left 6 or 7 spans per wave)
+    p.mfma_c = 3;                                             // (internal: tells pass_c_kernel to take the tail of a sorted list)
+    const int64_t n_full = p.n_edges >> 6;
+    int64_t blocks = (n_full + 3) / 4;
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (blocks < 1) blocks = 1;
+    const int64_t per_wave = (n_full + blocks * 4 - 1) / (blocks * 4), m = (per_wave + 47) / 48;
+    const int span_c = span_env > 0 ? span_env : (int)((per_wave + (m > 0 ? m : 1) - 1) / (m > 0 ? m : 1));
+    if (p.lazy_e) hipLaunchKernelGGL(pass_c_sorted_kernel<true>, dim3((int)blocks), dim3(256), 0, s, p, span_c > 0 ? span_c : 1);
+    else hipLaunchKernelGGL(pass_c_sorted_kernel<false>, dim3((int)blocks), dim3(256), 0, s, p, span_c > 0 ? span_c : 1);
+  } else if (p.mfma_c) {
+    // the any-order kernel.  Many edges (lists of >= 2^24 nodes, MTMC_PASS_C_GENERAL): short spans round-robin over a
+    // resident grid; few edges: one 64-edge chunk per wave, as many waves as there are chunks
     const int span_c = span_env > 0 ? span_env : (p.mfma_c == 2 ? 1 : 8);
     const int64_t spans = ((p.n_edges + 63) / 64 + span_c - 1) / span_c, blocks = (spans + 3) / 4;
-    hipLaunchKernelGGL(pass_c_mfma_kernel, dim3((int)(blocks > max_blocks ? max_blocks : blocks)), dim3(256), 0, s, p, span_c);
+    const int cap = max_blocks < 256 * 3 ? max_blocks : 256 * 3;           // 130 registers: three blocks per CU
+    hipLaunchKernelGGL(pass_c_mfma_kernel, dim3((int)(blocks > cap ? cap : blocks)), dim3(256), 0, s, p, span_c);
   }
   if (p.mfma_c != 2) hipLaunchKernelGGL(pass_c_kernel, dim3(edge_grid(p.n_edges, kTileC)), dim3(kTileC), 0, s, p);
   if (p.det && p.agg != 2) {

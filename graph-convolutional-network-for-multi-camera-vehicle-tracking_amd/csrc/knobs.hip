@@ -12,9 +12,12 @@ static Knobs read_knobs() {
   auto num = [](const char* name, long long dflt) { const char* v = getenv(name); return v ? atoll(v) : dflt; };
   k.pass_c_walk = on("MTMC_PASS_C_WALK");
   k.pass_c_small_min = num("MTMC_PASS_C_SMALL_MIN", 32768);
+  k.pass_c_general = on("MTMC_PASS_C_GENERAL");
   k.pass_c_span = (int)num("MTMC_PASS_C_SPAN", 0);
-  k.pass_c_blocks = (int)num("MTMC_PASS_C_BLOCKS", 256 * 3);      // what is resident: 130 VGPRs -> 3 waves per SIMD = 3 blocks per CU
-  if (k.pass_c_blocks < 1) k.pass_c_blocks = 256 * 3;
+  // 104 registers -> 4 blocks per CU are resident; twice that, so that CUs that finish early get more (config 4: 72.6 / 73.0 us
+  // with 1024 / 2048 blocks, config 5: 656 / 626 us)
+  k.pass_c_blocks = (int)num("MTMC_PASS_C_BLOCKS", 256 * 8);
+  if (k.pass_c_blocks < 1) k.pass_c_blocks = 256 * 8;
   k.gemm_fp32 = on("MTMC_GEMM_FP32");
   k.gemm_no_f16 = on("MTMC_GEMM_NO_F16");
   k.gemm_no_presplit = on("MTMC_GEMM_NO_PRESPLIT");

@@ -218,3 +218,47 @@ def test_many_node_variants(over):
     got, h = _gpu(m.cuda(), d, transposed_view=False)
     want64, h64 = _oracle(sd, params, d)
     _check(got, h, want64, h64, str(over))
+
+
+# ---- the sorted-list matrix-core pass C (pass_c_sorted_kernel) on lists whose 32-edge groups are NOT one or two rows ------
+def _mixed_degree_graph(n_dense, pairs_dense, n_sparse, pairs_sparse, seed, drop_tail=0):
+    """Row-sorted list of > 524 288 edges: a dense block of nodes (hundreds of edges per row: one- and two-row groups) followed
+    by a sparse block (a handful of edges per row: groups of 3-4 rows take the masked passes, groups of more rows the
+    per-register atomics), and isolated nodes in between.  drop_tail trims the list so that E % 64 takes a chosen value."""
+    g = torch.Generator().manual_seed(seed)
+    n = n_dense + n_sparse
+
+    def pairs(lo, cnt, m):
+        a = torch.randint(0, cnt, (m,), generator=g)
+        b = torch.randint(0, cnt - 1, (m,), generator=g)
+        b = b + (b >= a).to(b.dtype)
+        return a + lo, b + lo
+    a1, b1 = pairs(0, n_dense, pairs_dense)
+    a2, b2 = pairs(n_dense, n_sparse, pairs_sparse)
+    a, b = torch.cat([a1, a2]), torch.cat([b1, b2])
+    key, _ = torch.sort(torch.cat([a * n + b, b * n + a]))
+    if drop_tail:
+        key = key[:key.numel() - drop_tail]
+    ei = torch.stack([key // n, key % n])
+    x = torch.randn(n, 2048, generator=g)
+    ea = torch.rand(ei.shape[1], 2, generator=g)
+    return types.SimpleNamespace(x=x, edge_index=ei, edge_attr=ea)
+
+
+@pytest.mark.parametrize("tail", [0, 1, 37])
+def test_sorted_many_edge_list_with_low_degree_stretches(tail):
+    d = _mixed_degree_graph(1500, 270_000, 6000, 9_000, seed=77)
+    E = d.edge_index.shape[1]
+    drop = (E - tail) % 64                                   # leave exactly `tail` edges behind the last whole 64-edge chunk
+    if drop:
+        d = types.SimpleNamespace(x=d.x, edge_index=d.edge_index[:, :E - drop].contiguous(), edge_attr=d.edge_attr[:E - drop].contiguous())
+    E = d.edge_index.shape[1]
+    assert E > 524_288 and E % 64 == tail
+    m, sd, params = _model(2, 2)
+    plan = engine.ForwardEngine(m).plan(d.x.shape[0], E)
+    assert plan.pass_c == _lib.PASS_C_MFMA_SORTED, plan.pass_c
+    got, h = _gpu(m.cuda(), d, transposed_view=False)
+    want64, h64 = _oracle(sd, params, d)
+    _check(got, h, want64, h64, f"mixed degrees, E={E} (E % 64 = {tail})")
+    deg = torch.bincount(d.edge_index[0], minlength=d.x.shape[0])
+    assert int((deg == 0).sum()) > 0 and int(((deg > 0) & (deg < 8)).sum()) > 1000     # the stretches the test is about
