@@ -29,6 +29,19 @@ namespace mtmc {
 #ifndef SG_ABL
 #define SG_ABL 0          // timing ablations (tools/staged_ablate.sh); results are garbage for any value but 0
 #endif
+#ifndef SG_STAMP
+#define SG_STAMP 0        // 1: workgroup 0 records s_memtime at four points of every k-tile, per wave (tools/staged_stamps.py)
+#endif
+#if SG_STAMP
+constexpr int kSgStampKT = 64;
+__device__ unsigned long long g_sg_stamps[12 * kSgStampKT * 4];
+#define SG_T(kt, pt)                                                                                          \
+  do {                                                                                                        \
+    if (blockIdx.x == 0 && (kt) < kSgStampKT && lane == 0) g_sg_stamps[(wid * kSgStampKT + (kt)) * 4 + (pt)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define SG_T(kt, pt) do {} while (0)
+#endif
 
 
 constexpr int kSgBK = 32, kSgRowB = kSgBK * 2;                   // bytes per image row
@@ -103,7 +116,13 @@ __global__ __launch_bounds__(kSgNT) void gemm_staged_kernel(StagedGemmParams p, 
     sc[2] = ldexpf(1.f, ea - 14);
   }
   __syncthreads();
-  const float sa = sc[0];
+  // the A scale (a power of two: exact) goes into the affine: relu(s y + t) * sa == relu((s sa) y + (t sa)), four multiplies
+  // per float4 less in the producers' conversion
+  {
+    const float sa = sc[0];
+    for (int kk = threadIdx.x; kk < p.K; kk += kSgNT) { s_in[kk] *= sa; t_in[kk] *= sa; }
+  }
+  __syncthreads();
   const int nk = p.K / kSgBK;
 
   f32x4v acc[4][TJ];
@@ -150,27 +169,33 @@ __global__ __launch_bounds__(kSgNT) void gemm_staged_kernel(StagedGemmParams p, 
           *reinterpret_cast<uint2*>(st + AIMG + a_dst[h]) = uint2{__float_as_uint(v.z), __float_as_uint(v.w)};
           continue;
         }
-        // relu(bn(y)) scaled into fp16's range, then h1 = rtz(x), h2 = rtz(x - h1) (exact residual; see gemm_bn.hip `put`)
-        const float x0 = fmaxf(fmaf(v.x, s4.x, t4.x), 0.f) * sa, x1 = fmaxf(fmaf(v.y, s4.y, t4.y), 0.f) * sa;
-        const float x2 = fmaxf(fmaf(v.z, s4.z, t4.z), 0.f) * sa, x3 = fmaxf(fmaf(v.w, s4.w, t4.w), 0.f) * sa;
+        // relu(bn(y)) scaled into fp16's range (the scale sits in s4 / t4), then h1 = rtz(x), h2 = rtz(x - h1) (exact
+        // residual; see gemm_bn.hip `put`)
+        const float x0 = fmaxf(fmaf(v.x, s4.x, t4.x), 0.f), x1 = fmaxf(fmaf(v.y, s4.y, t4.y), 0.f);
+        const float x2 = fmaxf(fmaf(v.z, s4.z, t4.z), 0.f), x3 = fmaxf(fmaf(v.w, s4.w, t4.w), 0.f);
         const h2_t a01 = __builtin_amdgcn_cvt_pkrtz(x0, x1), a23 = __builtin_amdgcn_cvt_pkrtz(x2, x3);
         const h2_t b01 = __builtin_amdgcn_cvt_pkrtz(x0 - (float)a01[0], x1 - (float)a01[1]);
         const h2_t b23 = __builtin_amdgcn_cvt_pkrtz(x2 - (float)a23[0], x3 - (float)a23[1]);
         uint2 q1, q2;
         q1.x = __builtin_bit_cast(unsigned, a01); q1.y = __builtin_bit_cast(unsigned, a23);
         q2.x = __builtin_bit_cast(unsigned, b01); q2.y = __builtin_bit_cast(unsigned, b23);
-        *reinterpret_cast<uint2*>(st + a_dst[h]) = q1;
-        *reinterpret_cast<uint2*>(st + AIMG + a_dst[h]) = q2;
+        unsigned char* d = st + a_dst[h];                  // one address, the second piece at a constant offset
+        *reinterpret_cast<uint2*>(d) = q1;
+        *reinterpret_cast<uint2*>(d + AIMG) = q2;
       }
     };
     // One k-tile of producer work.  A(k) lives in register set k % 3: tile kt+3 is loaded into set `ld` = kt % 3 (free:
     // A(kt) went to LDS one k-tile ago) while tile kt+1, loaded TWO k-tiles ago, is converted out of set `cv` = (kt+1) % 3.
     // ld / cv are literals at the call sites, so the register arrays are indexed statically after inlining.
     auto step = [&](int kt, int ld, int cv) {
+      SG_T(kt, 0);
       if (kt + 3 < nk) load_a(kt + 3, ld);
       if (kt + 1 < nk) convert_a(kt + 1, cv);            // -> A stage (kt+1)&1: the consumers left it at the last barrier
+      SG_T(kt, 1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      SG_T(kt, 2);
       __builtin_amdgcn_s_barrier();
+      SG_T(kt, 3);
     };
     load_a(0, 0);
     if (nk > 1) load_a(1, 1);
@@ -227,6 +252,7 @@ __global__ __launch_bounds__(kSgNT) void gemm_staged_kernel(StagedGemmParams p, 
     }
     __builtin_amdgcn_s_barrier();                        // pairs with the producers' pipeline-fill barrier
     for (int kt = 0; kt < nk; ++kt) {
+      SG_T(kt, 0);
       const bool more = kt + 2 < nk;                     // W(kt+2) -> W stage (kt+2)%3 = (kt-1)%3: everyone left it at the last barrier
       const unsigned char* st = smem + (kt % kSgNW) * WST;
       const unsigned char* as = smem + A0 + (kt & 1) * AST;
@@ -276,9 +302,12 @@ __global__ __launch_bounds__(kSgNT) void gemm_staged_kernel(StagedGemmParams p, 
       }
       // this wave's fragment reads are done (the stages may be refilled), and its share of W(kt+1) has landed -- W(kt+2),
       // issued during this k-tile, stays in flight across the barrier
+      SG_T(kt, 1);
       if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * WJ) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      SG_T(kt, 2);
       __builtin_amdgcn_s_barrier();
+      SG_T(kt, 3);
     }
   }
 
@@ -448,3 +477,9 @@ int launch_gemm_staged(const StagedGemmParams& p, hipStream_t s) {
 }
 
 }  // namespace mtmc
+
+#if SG_STAMP
+extern "C" int mtmc_dbg_staged_stamps(unsigned long long* out) {    // host buffer of 12 * 64 * 4 entries
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mtmc::g_sg_stamps), sizeof(mtmc::g_sg_stamps));
+}
+#endif
