@@ -68,6 +68,25 @@ __device__ __forceinline__ float wave_sum_f32(float v) {   // total in lane 63
   return v;
 }
 
+// Wave totals of FOUR per-lane values in ten instructions (four separate DPP sums take 24): two v_permlane32_swap + adds
+// fold the wave's halves so that lanes 0-31 hold v0 / v2 and lanes 32-63 v1 / v3 partials, one v_permlane16_swap + add
+// folds the 16-lane rows, four row_shr steps finish inside a row.  The total of value {0, 2, 1, 3}[r] ends up in the LAST
+// lane of row r (lanes 15, 31, 47, 63); wave_sum4_slot(lane) names the value a lane holds.
+__device__ __forceinline__ float wave_sum4_f32(float v0, float v1, float v2, float v3) {
+  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v2), __float_as_uint(v3), false, false);
+  const float s01 = __uint_as_float(a[0]) + __uint_as_float(a[1]);   // lanes 0-31: v0[l] + v0[l+32]; lanes 32-63: the same of v1
+  const float s23 = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+  const auto c = __builtin_amdgcn_permlane16_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);
+  float u = __uint_as_float(c[0]) + __uint_as_float(c[1]);           // rows 0..3: v0, v2, v1, v3 (16 partial sums each)
+  u = dpp_add_f32<0x111, 0xf>(u);
+  u = dpp_add_f32<0x112, 0xf>(u);
+  u = dpp_add_f32<0x114, 0xf>(u);
+  u = dpp_add_f32<0x118, 0xf>(u);
+  return u;
+}
+__device__ __forceinline__ int wave_sum4_slot(int lane) { return ((lane >> 4) & 1) * 2 + (lane >> 5); }   // rows 0..3 -> 0, 2, 1, 3
+
 // dst[key*stride + j] += v[j] for every active lane, with lanes that carry the same key next to each other reduced
 // in the wave first: one DPP sum + NV atomics when the whole wave shares a key (the common case on row-sorted edge
 // lists, where per-lane atomics would all hit one address), otherwise a segmented scan and one atomic per run.

@@ -326,7 +326,19 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
   // the first trip's operands do not depend on the statistics: fetch them before waiting for those
   int rr[kEPT];
   float4 zz[kEPT];
+  // a block's tile of 256 * kEPT edges is either whole (every tile but the list's last: no per-edge bounds checks, the
+  // addresses are a block-uniform base + the thread index) or the last, partial one
+  auto whole = [&](int64_t b) { return b - threadIdx.x + 256 * kEPT <= p.n_edges; };      // block-uniform
   auto fetch = [&](int64_t b) {
+    if (whole(b)) {
+      const int64_t t0 = b - threadIdx.x;
+#pragma unroll
+      for (int i = 0; i < kEPT; ++i) {
+        rr[i] = (p.row32 + t0 + i * 256)[threadIdx.x];
+        zz[i] = reinterpret_cast<const float4*>(p.e_buf + (t0 + i * 256) * 4)[threadIdx.x];
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < kEPT; ++i) {
       const int64_t e = b + i * 256;
@@ -350,13 +362,14 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
 #pragma unroll
   for (int i = 0; i < 14; ++i) acc[i] = 0;
   while (base < e_end) {
+    const bool full = whole(base);
     float vv[kEPT][4];
 #pragma unroll
     for (int i = 0; i < kEPT; ++i) {
       const int64_t e = base + i * 256;
 #pragma unroll
       for (int k = 0; k < 4; ++k) vv[i][k] = 0.f;
-      if (e < p.n_edges) {
+      if (full || e < p.n_edges) {
         const float z4[4] = {zz[i].x, zz[i].y, zz[i].z, zz[i].w};
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -367,8 +380,8 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
 #pragma unroll
     for (int i = 0; i < kEPT; ++i) {
       const int64_t e = base + i * 256;
-      if (e - lane >= p.n_edges) continue;         // whole wave past the end (wave-uniform)
-      const bool active = e < p.n_edges;
+      if (!full && e - lane >= p.n_edges) continue;   // whole wave past the end (wave-uniform)
+      const bool active = full || e < p.n_edges;
       float* v = vv[i];
       const int r = rr[i];
 #pragma unroll
@@ -381,13 +394,24 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
       // one DPP wave sum per channel and 4 atomics.  Otherwise a segmented inclusive scan over the wave (any row
       // order), then one fp64 atomic per run and channel.
       const int r0 = __builtin_amdgcn_readfirstlane(r);
-      if (__all(r == r0) && r0 >= 0) {
-        float t[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) t[k] = wave_sum_f32(v[k]);
-        if (lane == kWaveSumLane) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) unsafeAtomicAdd(p.seg + (int64_t)r0 * 4 + k, (double)t[k]);
+      const unsigned long long in_first = __ballot(r == r0);
+      if (in_first == ~0ull && r0 >= 0) {
+        const float t = wave_sum4_f32(v[0], v[1], v[2], v[3]);      // lanes 15 / 31 / 47 / 63: channels 0 / 2 / 1 / 3
+        if ((lane & 15) == 15) unsafeAtomicAdd(p.seg + (int64_t)r0 * 4 + wave_sum4_slot(lane), (double)t);
+        continue;
+      }
+      // two rows in a whole wave (the next most common case on row-sorted lists at ~100 edges per row): the first row's
+      // share and the total by the same ten-instruction sums, the second row's share as their difference (e' >= 0: no
+      // cancellation beyond the total's rounding)
+      const int r1 = __builtin_amdgcn_readlane(r, 63);
+      if (r0 >= 0 && r1 >= 0 && (in_first | __ballot(r == r1)) == ~0ull) {
+        const bool first = r == r0;
+        const float tot = wave_sum4_f32(v[0], v[1], v[2], v[3]);
+        const float fst = wave_sum4_f32(first ? v[0] : 0.f, first ? v[1] : 0.f, first ? v[2] : 0.f, first ? v[3] : 0.f);
+        if ((lane & 15) == 15) {
+          const int k = wave_sum4_slot(lane);
+          unsafeAtomicAdd(p.seg + (int64_t)r0 * 4 + k, (double)fst);
+          unsafeAtomicAdd(p.seg + (int64_t)r1 * 4 + k, (double)(tot - fst));
         }
         continue;
       }
