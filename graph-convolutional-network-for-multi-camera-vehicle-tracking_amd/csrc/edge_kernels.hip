@@ -185,17 +185,46 @@ struct PrevAffine { float s[4], t[4]; };   // BatchNorm affine of the previous r
 // result is stored (the z1 store may alias every input as far as the compiler can tell: interleaved, each edge's load
 // chain would start only after the previous edge's store).
 struct EdgeIn { float4 pr, pc, ev; float a0, a1; };
+// Non-temporal access on the edge streams (tools/edge_nt_sweep.sh; config 4 / config 5, all edge passes of a forward, us):
+//   none 737 / 8916 | PA 3 698 / 8892 | PA 4 717 / 8759 | PA 7 708 / 8651 | PA 3 + PC 735 / 8876 | PA 3 + PB 684 / 8698 |
+//   PA 7 + PC + PB 724 / 8487.
+// The streams of a 10M-edge list (z1: 160 MB) survive in the 256 MB Infinity Cache from one pass to the next unless a pass
+// in between pushes them out; those of a 100M-edge list never do.  Taken: row / col ids and the previous z1 non-temporal
+// in pass A (its L2 keeps the randomly gathered Pc table instead: 117 -> 99 us per launch at config 4), pass B's stream
+// loads non-temporal (48 -> 40 us), z1 stored normally and read normally by pass C so that the next pass finds it cached --
+// the regime of config 4 and of an eighth of config 5.
+#ifndef PA_NT
+#define PA_NT 3           // pass A: 1 row / col ids, 2 previous z1, 4 the z1 store
+#endif
+#ifndef PC_NT
+#define PC_NT 0           // stream loads of pass_c_sorted_kernel
+#endif
+#ifndef PB_NT
+#define PB_NT 1           // stream loads of pass B (whole tiles)
+#endif
 
 template <int MODE>
 __device__ __forceinline__ void edge_load(const RoundParams& p, int64_t e, EdgeIn& in) {
+#if PA_NT & 1
+  const int r = __builtin_nontemporal_load(p.row32 + e), col = __builtin_nontemporal_load(p.col32 + e);
+#else
   const int r = p.row32[e], col = p.col32[e];
+#endif
   // P = [Pr: N x 4 | Pc: N x 4]: the randomly gathered half is a compact 16 B/node table (four nodes per 64-byte sector)
   in.pr = *reinterpret_cast<const float4*>(p.P + (int64_t)r * 4);
   in.pc = *reinterpret_cast<const float4*>(p.P + ((int64_t)p.n_nodes + col) * 4);
   in.a0 = in.a1 = 0.f;
   in.ev = make_float4(0.f, 0.f, 0.f, 0.f);
   if (MODE != 0) load_attr(p.attr, p.enc.fe, e, in.a0, in.a1);
+#if PA_NT & 2
+  if (!(MODE & 1)) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p.e_prev) + e);
+    in.ev = make_float4(v[0], v[1], v[2], v[3]);
+  }
+#else
   if (!(MODE & 1)) in.ev = reinterpret_cast<const float4*>(p.e_prev)[e];
+#endif
 }
 
 template <int MODE, bool DROP>
@@ -284,7 +313,15 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 5 : 1)) void pass_a_kernel(RoundP
     edge_z1<MODE, DROP>(p, ks, c, pa, e, in, z);
     // the random 16-byte P[col] gather is what bounds this pass (one cache line per lane): do it once and
     // hand z1 to pass B through memory instead of gathering again there
+#if PA_NT & 4
+    {
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      f4v zv = {z[0], z[1], z[2], z[3]};
+      __builtin_nontemporal_store(zv, reinterpret_cast<f4v*>(p.e_buf) + e);
+    }
+#else
     reinterpret_cast<float4*>(p.e_buf)[e] = make_float4(z[0], z[1], z[2], z[3]);
+#endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       acc[k] += z[k];
@@ -334,8 +371,15 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
       const int64_t t0 = b - threadIdx.x;
 #pragma unroll
       for (int i = 0; i < kEPT; ++i) {
+#if PB_NT
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        rr[i] = __builtin_nontemporal_load(p.row32 + t0 + i * 256 + threadIdx.x);
+        const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p.e_buf + (t0 + i * 256) * 4) + threadIdx.x);
+        zz[i] = make_float4(v[0], v[1], v[2], v[3]);
+#else
         rr[i] = (p.row32 + t0 + i * 256)[threadIdx.x];
         zz[i] = reinterpret_cast<const float4*>(p.e_buf + (t0 + i * 256) * 4)[threadIdx.x];
+#endif
       }
       return;
     }
@@ -970,8 +1014,17 @@ __global__ __launch_bounds__(256) void pass_c_sorted_kernel(RoundParams p, int s
     auto fetch = [&](int c, int slot) {                         // whole chunks only: c is clamped to the last one
       const int cc = min(c, n_full - 1);
       const int64_t e0 = (int64_t)cc * 64;
+#if PC_NT
+      {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p.e_out + e0 * 4) + lane);
+        ev[slot] = make_float4(v[0], v[1], v[2], v[3]);
+        rw[slot] = __builtin_nontemporal_load(p.row32 + e0 + lane);
+      }
+#else
       ev[slot] = reinterpret_cast<const float4*>(p.e_out + e0 * 4)[lane];
       rw[slot] = (p.row32 + e0)[lane];
+#endif
     };
     auto lookup = [&](int slot) {                               // the chunk's row ids have landed: its four rows, its Q operands
       rows[slot][0] = __builtin_amdgcn_readlane(rw[slot], 0);
