@@ -305,6 +305,17 @@ __device__ __forceinline__ void edge_enc_out(const EdgeEncParams& p, const EdgeE
   }
 }
 
+// the same for a stream's last reader (non-temporal: the line is not kept in L2 / Infinity Cache)
+__device__ __forceinline__ void load_attr_nt(const float* attr, int fe, int64_t e, float& a0, float& a1) {
+  if (fe == 2) {
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    const f2v v = __builtin_nontemporal_load(reinterpret_cast<const f2v*>(attr) + e);
+    a0 = v[0]; a1 = v[1];
+  } else {
+    a0 = __builtin_nontemporal_load(attr + e); a1 = 0.f;
+  }
+}
+
 __device__ __forceinline__ void load_attr(const float* attr, int fe, int64_t e, float& a0, float& a1) {
   if (fe == 2) {
     const float2 v = reinterpret_cast<const float2*>(attr)[e];

@@ -194,7 +194,7 @@ struct EdgeIn { float4 pr, pc, ev; float a0, a1; };
 // loads non-temporal (48 -> 40 us), z1 stored normally and read normally by pass C so that the next pass finds it cached --
 // the regime of config 4 and of an eighth of config 5.
 #ifndef PA_NT
-#define PA_NT 3           // pass A: 1 row / col ids, 2 previous z1, 4 the z1 store
+#define PA_NT 11          // pass A: 1 row / col ids, 2 previous z1, 4 the z1 store, 8 edge_attr in the first round (126 -> 120 us)
 #endif
 #ifndef PC_NT
 #define PC_NT 0           // stream loads of pass_c_sorted_kernel
@@ -215,7 +215,8 @@ __device__ __forceinline__ void edge_load(const RoundParams& p, int64_t e, EdgeI
   in.pc = *reinterpret_cast<const float4*>(p.P + ((int64_t)p.n_nodes + col) * 4);
   in.a0 = in.a1 = 0.f;
   in.ev = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (MODE != 0) load_attr(p.attr, p.enc.fe, e, in.a0, in.a1);
+  if (MODE == 1 && (PA_NT & 8)) load_attr_nt(p.attr, p.enc.fe, e, in.a0, in.a1);   // first round, no reattachment: the last reader
+  else if (MODE != 0) load_attr(p.attr, p.enc.fe, e, in.a0, in.a1);
 #if PA_NT & 2
   if (!(MODE & 1)) {
     typedef float f4v __attribute__((ext_vector_type(4)));
