@@ -187,7 +187,7 @@ struct PrevAffine { float s[4], t[4]; };   // BatchNorm affine of the previous r
 struct EdgeIn { float4 pr, pc, ev; float a0, a1; };
 // Non-temporal access on the edge streams (tools/edge_nt_sweep.sh; config 4 / config 5, all edge passes of a forward, us):
 //   none 737 / 8916 | PA 3 698 / 8892 | PA 4 717 / 8759 | PA 7 708 / 8651 | PA 3 + PC 735 / 8876 | PA 3 + PB 684 / 8698 |
-//   PA 7 + PC + PB 724 / 8487.
+//   PA 7 + PC + PB 724 / 8487.  With PA 11 + PB: 675 / 8714; PA 15 + PB: 689 / 8510 (hence RoundParams::stream_z1).
 // The streams of a 10M-edge list (z1: 160 MB) survive in the 256 MB Infinity Cache from one pass to the next unless a pass
 // in between pushes them out; those of a 100M-edge list never do.  Taken: row / col ids and the previous z1 non-temporal
 // in pass A (its L2 keeps the randomly gathered Pc table instead: 117 -> 99 us per launch at config 4), pass B's stream
@@ -314,15 +314,13 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 5 : 1)) void pass_a_kernel(RoundP
     edge_z1<MODE, DROP>(p, ks, c, pa, e, in, z);
     // the random 16-byte P[col] gather is what bounds this pass (one cache line per lane): do it once and
     // hand z1 to pass B through memory instead of gathering again there
-#if PA_NT & 4
-    {
+    if ((PA_NT & 4) || p.stream_z1) {                 // (block-uniform)
       typedef float f4v __attribute__((ext_vector_type(4)));
       f4v zv = {z[0], z[1], z[2], z[3]};
       __builtin_nontemporal_store(zv, reinterpret_cast<f4v*>(p.e_buf) + e);
+    } else {
+      reinterpret_cast<float4*>(p.e_buf)[e] = make_float4(z[0], z[1], z[2], z[3]);
     }
-#else
-    reinterpret_cast<float4*>(p.e_buf)[e] = make_float4(z[0], z[1], z[2], z[3]);
-#endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       acc[k] += z[k];
@@ -1246,7 +1244,12 @@ static void launch_pass_a_mode(const RoundParams& p, hipStream_t s) {
     default: hipLaunchKernelGGL((pass_a_kernel<kPassAEpt, MODE, false>), dim3(edge_grid(p.n_edges, 256 * kPassAEpt)), dim3(256), 0, s, p);
   }
 }
-void launch_pass_a(const RoundParams& p, hipStream_t s) {
+void launch_pass_a(const RoundParams& p0, hipStream_t s) {
+  RoundParams p = p0;
+  // z1 (16 B / edge) is read by pass B, pass C and the next pass A: stored with the default policy it waits for them in the
+  // 256 MB Infinity Cache; a z1 that does not fit there only pushes everything else out on its way (config 5: -2 % on the
+  // edge passes with a streaming store, config 4: +2 %)
+  p.stream_z1 = p.n_edges * 16 > (int64_t)256 << 20;
   switch ((p.first_round ? 1 : 0) | (p.reattach_edges ? 2 : 0)) {
     case 0: launch_pass_a_mode<0>(p, s); break;
     case 1: launch_pass_a_mode<1>(p, s); break;

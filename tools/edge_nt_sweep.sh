@@ -7,7 +7,7 @@ run() { rm -rf /tmp/ks; timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /t
 import csv
 d={r['Name'][6:36]:(int(r['Calls']),float(r['AverageNs'])/1000) for r in csv.DictReader(open('/tmp/ks/x_kernel_stats.csv')) if 'pass_' in r['Name']}
 print(' | '.join(f'{k[5:22]} {t:7.1f}' for k,(c,t) in sorted(d.items())), '| edge passes per fwd', round(sum(c*t for c,t in d.values())/(max(c for c,_ in d.values())/3),1))"; }
-for v in "-DPA_NT=0" "-DPA_NT=3" "-DPA_NT=4" "-DPA_NT=7" "-DPA_NT=3 -DPC_NT=1" "-DPA_NT=3 -DPB_NT=1" "-DPA_NT=7 -DPC_NT=1 -DPB_NT=1" "-DPA_NT=2"; do
+for v in "-DPA_NT=11 -DPB_NT=1" "-DPA_NT=15 -DPB_NT=1" "-DPA_NT=11 -DPB_NT=1 -DPC_NT=1" "-DPA_NT=15 -DPB_NT=1 -DPC_NT=1"; do
   (cd $CS && rm -f edge_kernels.o && make -s EXTRA="$v" libmtmc_mpn.so > /dev/null 2>&1)
   echo "== $v"; run cfg4 20; run cfg5 3
 done
