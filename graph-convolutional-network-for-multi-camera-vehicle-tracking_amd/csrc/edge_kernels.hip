@@ -518,15 +518,15 @@ __global__ __launch_bounds__(256) void agg_fixup_kernel(RoundParams p) {
   for (int64_t i = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5); i < p.n_nodes; i += stride) {
     const int d = p.deg[i];
     if (d == 0) continue;
-    const int64_t s = p.row_start[i], t = s + d;
-    const int64_t cs = s >> 5, ce = (t - 1) >> 5;
+    const int64_t s = p.row_start[i], t = s + d, len = p.det_len;      // len: edges per carry chunk (walk: 32; sorted: a span)
+    const int64_t cs = s / len, ce = (t - 1) / len;
     float v;
     if (cs == ce) {
-      if ((s & 31) == 0) v = p.carry[(cs * 2 + 0) * kH + k];
-      else if ((t & 31) == 0 || t == p.n_edges) v = p.carry[(cs * 2 + 1) * kH + k];
+      if (s % len == 0) v = p.carry[(cs * 2 + 0) * kH + k];
+      else if (t % len == 0 || t == p.n_edges) v = p.carry[(cs * 2 + 1) * kH + k];
       else continue;                                 // strictly inside its chunk: already stored
     } else {
-      v = p.carry[(cs * 2 + ((s & 31) == 0 ? 0 : 1)) * kH + k];
+      v = p.carry[(cs * 2 + (s % len == 0 ? 0 : 1)) * kH + k];
       for (int64_t c = cs + 1; c <= ce; ++c) v += p.carry[(c * 2 + 0) * kH + k];
     }
     p.h_acc[i * kH + k] = v;
@@ -544,7 +544,8 @@ __global__ __launch_bounds__(kTileC) void pass_c_kernel(RoundParams p) {
   // many-edge row-sorted list: pass_c_sorted_kernel, launched just before, did every whole 64-edge chunk; what is left for
   // this kernel are the < 64 edges behind the last one
   int64_t e_first = 0;
-  if (p.mfma_c == 1 && p.flags[0] == 0) return;  // (MTMC_PASS_C_GENERAL: pass_c_mfma_kernel did all of a sorted list)
+  if ((p.mfma_c == 1 || p.mfma_c == 4) && p.flags[0] == 0) return;  // the matrix-core kernel did all of a sorted list
+                                                                     // (1: MTMC_PASS_C_GENERAL, 4: deterministic mode)
   if (p.mfma_c == 3 && p.flags[0] == 0) {
     e_first = p.n_edges & ~(int64_t)63;
     if (e_first == p.n_edges) return;
@@ -942,7 +943,11 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
 //  * the three-deep pipeline is unrolled by three with the stage registers renamed: no register moves.
 // Groups that touch three or more rows (low-degree stretches) take the masked pass per distinct row, as above.
 // ------------------------------------------------------------------------------------------------
-template <bool LAZY>
+// DET (MTMC_F_DETERMINISTIC): no atomics.  A span's first run goes to carry[span][0], its last run (if different) to
+// carry[span][1], runs strictly inside a span are complete rows and are stored; agg_fixup_kernel adds a row's pieces in span
+// order (the walk's scheme, flush_run above, with spans of span_c * 64 edges for its 32-edge chunks).  The < 64 edges behind
+// the last whole chunk are then taken here too, by the wave that owns the last span, through the masked passes.
+template <bool LAZY, bool DET>
 __global__ __launch_bounds__(256) void pass_c_sorted_kernel(RoundParams p, int span_c) {
   __shared__ double st[10 + 64];
   __shared__ double st1[8];
@@ -984,25 +989,75 @@ __global__ __launch_bounds__(256) void pass_c_sorted_kernel(RoundParams p, int s
   const unsigned koff = (unsigned)k * 4u;
 
   const int n_full = (int)(p.n_edges >> 6);                  // whole chunks (launch_pass_c: fewer than 2^31 of them)
-  const int n_spans = (n_full + span_c - 1) / span_c;
+  const int n_tail = (int)(p.n_edges & 63);                  // edges behind them (DET: taken here; else by pass_c_kernel)
+  const int n_spans = ((DET && n_tail ? n_full + 1 : n_full) + span_c - 1) / span_c;
   const int wave_stride = (int)gridDim.x * 4;
   for (int span = (int)blockIdx.x * 4 + wid; span < n_spans; span += wave_stride) {
     int cur = -1;                 // wave-uniform: the row whose partial sum `run` holds (this lane's channel, this half's edges)
     float run = 0.f;
-    auto flush = [&]() {
+    bool first_run = true;        // DET: nothing of this span has been flushed yet
+    auto flush = [&](bool last) {
       if (cur >= 0) {
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(run), __float_as_uint(run), false, false);
         const float tot = run + __uint_as_float(hi == 0 ? sw[1] : sw[0]);
-        if (hi == 0) unsafeAtomicAdd(p.h_acc + (int64_t)cur * kH + k, tot);
+        if (!DET) {
+          if (hi == 0) unsafeAtomicAdd(p.h_acc + (int64_t)cur * kH + k, tot);
+        } else if (hi == 0) {
+          if (first_run) p.carry[((int64_t)span * 2 + 0) * kH + k] = tot;
+          else if (last) p.carry[((int64_t)span * 2 + 1) * kH + k] = tot;
+          else p.h_acc[(int64_t)cur * kH + k] = tot;             // a row that began and ended inside this span
+        }
+        first_run = false;
       }
     };
     auto account = [&](int r, float part) {                     // add a group's partial sum to row r's run
       if (r != cur) {
-        flush();
+        flush(false);
         cur = r;
         run = 0.f;
       }
       run += part;
+    };
+    // groups that are not one or two rows: a masked pass per distinct row (up to four; DET: any number), else every
+    // register goes to its own row with one atomic (bounded cost, no run bookkeeping).  gm: the group's valid edges.
+    auto slow_group = [&](const f32x16c& acc, int rwc, int g, unsigned gm) {
+      int n_rows = 0;
+      if (!DET) {
+        unsigned left = gm;
+        while (left != 0 && n_rows <= 4) {
+          const int r = __builtin_amdgcn_readfirstlane(__shfl(rwc, 32 * g + __ffs(left) - 1, 64));
+          left &= ~((unsigned)(__ballot(rwc == r) >> (32 * g)));
+          ++n_rows;
+        }
+      }
+      if (!DET && n_rows > 4) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int off = (i & 3) + 8 * (i >> 2) + 4 * hi;
+          const int r = __shfl(rwc, 32 * g + off, 64);
+          if ((gm >> off) & 1u) {
+            const float c0 = fmaf(sk, p.Q[(int64_t)r * kH + k], cb);
+            unsafeAtomicAdd(p.h_acc + (int64_t)r * kH + k, fmaxf(acc[i] + c0, 0.f));
+          }
+        }
+        return;
+      }
+      unsigned done = 0;
+      while (done != gm) {
+        const int pos = __ffs(gm & ~done) - 1;
+        const int r = __builtin_amdgcn_readfirstlane(__shfl(rwc, 32 * g + pos, 64));
+        const unsigned same = (unsigned)(__ballot(rwc == r) >> (32 * g)) & gm & ~done;
+        done |= same;
+        const float c0 = fmaf(sk, p.Q[(int64_t)r * kH + k], cb);
+        const unsigned mine = same >> (4 * hi);               // bit (i&3) + 8(i>>2): register i's edge of this half-wave
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float tt = fmaxf(acc[i] + c0, 0.f);
+          sacc += ((mine >> ((i & 3) + 8 * (i >> 2))) & 1u) ? tt : 0.f;
+        }
+        account(r, sacc);
+      }
     };
     const int c_beg = span * span_c, c_end = min(n_full, c_beg + span_c);
     // stage registers: chunk c lives in slot c % 3 (literal at every use after inlining)
@@ -1124,43 +1179,7 @@ __global__ __launch_bounds__(256) void pass_c_sorted_kernel(RoundParams p, int s
           f32x16c acc = {};
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(xy[g]), b0, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(zw[g]), b1, acc, 0, 0, 0);
-          // three or more rows in the group: one masked pass per distinct row (up to four), else every register goes to
-          // its own row with one atomic (bounded cost, no run bookkeeping)
-          int n_rows = 0;
-          {
-            unsigned left = 0xffffffffu;
-            while (left != 0 && n_rows <= 4) {
-              const int r = __builtin_amdgcn_readfirstlane(__shfl(rwc, 32 * g + __ffs(left) - 1, 64));
-              left &= ~((unsigned)(__ballot(rwc == r) >> (32 * g)));
-              ++n_rows;
-            }
-          }
-          if (n_rows > 4) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              const int off = (i & 3) + 8 * (i >> 2) + 4 * hi;
-              const int r = __shfl(rwc, 32 * g + off, 64);
-              const float c0 = fmaf(sk, p.Q[(int64_t)r * kH + k], cb);
-              unsafeAtomicAdd(p.h_acc + (int64_t)r * kH + k, fmaxf(acc[i] + c0, 0.f));
-            }
-            continue;
-          }
-          unsigned done = 0;
-          while (done != 0xffffffffu) {
-            const int pos = __ffs(~done) - 1;
-            const int r = __builtin_amdgcn_readfirstlane(__shfl(rwc, 32 * g + pos, 64));
-            const unsigned same = (unsigned)(__ballot(rwc == r) >> (32 * g)) & ~done;
-            done |= same;
-            const float c0 = fmaf(sk, p.Q[(int64_t)r * kH + k], cb);
-            const unsigned mine = same >> (4 * hi);             // bit (i&3) + 8(i>>2): register i's edge of this half-wave
-            float sacc = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              const float tt = fmaxf(acc[i] + c0, 0.f);
-              sacc += ((mine >> ((i & 3) + 8 * (i >> 2))) & 1u) ? tt : 0.f;
-            }
-            account(r, sacc);
-          }
+          slow_group(acc, rwc, g, 0xffffffffu);
         }
       }
     };
@@ -1172,7 +1191,37 @@ __global__ __launch_bounds__(256) void pass_c_sorted_kernel(RoundParams p, int s
       if (c + 1 < c_end) step(c + 1, 1, 2, 0);
       if (c + 2 < c_end) step(c + 2, 2, 0, 1);
     }
-    flush();
+    if (DET && n_tail && span == n_spans - 1) {
+      // the partial last chunk (clamped addresses, masked passes only)
+      const int64_t e = (int64_t)n_full * 64 + lane;
+      const bool valid = lane < n_tail;
+      const int64_t ec = valid ? e : p.n_edges - 1;
+      float4 e4 = reinterpret_cast<const float4*>(p.e_out)[ec];
+      const int rwc = valid ? p.row32[ec] : -1;
+      if (LAZY) {
+        e4.x = fmaxf(fmaf(e4.x, s1[0], t1[0]), 0.f); e4.y = fmaxf(fmaf(e4.y, s1[1], t1[1]), 0.f);
+        e4.z = fmaxf(fmaf(e4.z, s1[2], t1[2]), 0.f); e4.w = fmaxf(fmaf(e4.w, s1[3], t1[3]), 0.f);
+      }
+      if (p.logits != nullptr && valid) {
+        for (int cc = 0; cc < p.n_classes; ++cc) {
+          const float* w = p.cls_w + cc * 4;
+          p.logits[e * p.n_classes + cc] = fmaf(w[3], e4.w, fmaf(w[2], e4.z, fmaf(w[1], e4.y, fmaf(w[0], e4.x, p.cls_b[cc]))));
+        }
+      }
+      const auto xy = __builtin_amdgcn_permlane32_swap(__float_as_uint(e4.x), __float_as_uint(e4.y), false, false);
+      const auto zw = __builtin_amdgcn_permlane32_swap(__float_as_uint(e4.z), __float_as_uint(e4.w), false, false);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int nv = n_tail - 32 * g;
+        const unsigned gm = nv >= 32 ? 0xffffffffu : (nv > 0 ? ((1u << nv) - 1u) : 0u);
+        if (gm == 0) break;
+        f32x16c acc = {};
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(xy[g]), b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(zw[g]), b1, acc, 0, 0, 0);
+        slow_group(acc, rwc, g, gm);
+      }
+    }
+    flush(true);
   }
 }
 
@@ -1270,14 +1319,16 @@ void launch_pass_b(const RoundParams& p, hipStream_t s) {
 // per row.  MTMC_PASS_C_WALK=1 keeps the walk everywhere (A/B).
 int plan_pass_c(int agg, bool deterministic, bool dropout, int64_t n_edges, double avg_degree) {
   const Knobs& kn = knobs();
-  if (kn.pass_c_walk || agg == 2 || deterministic || dropout || avg_degree < 24.0) return 0;
-  if (n_edges > kSmallEdges) return 1;
+  if (kn.pass_c_walk || agg == 2 || dropout || avg_degree < 24.0) return 0;
+  if (n_edges > kSmallEdges) return (deterministic && kn.pass_c_general) ? 0 : 1;   // (sorted kernel: also in deterministic mode)
+  if (deterministic) return 0;                               // few edges: fixed-order sums live in the walk
   return n_edges >= kn.pass_c_small_min ? 2 : 0;
 }
 int plan_edges_per_thread(int64_t n_edges) { return pick_ept(n_edges); }
 
 void launch_pass_c(const RoundParams& p0, hipStream_t s) {
   RoundParams p = p0;
+  p.det_len = 32;
   p.mfma_c = plan_pass_c(p.agg, p.det != 0, p.drop_n.on != 0, p.n_edges, p.avg_degree);
   const int span_env = knobs().pass_c_span, max_blocks = knobs().pass_c_blocks;
   if (p.mfma_c == 1 && !knobs().pass_c_general && p.n_nodes < (1ll << 24)) {
@@ -1286,15 +1337,25 @@ void launch_pass_c(const RoundParams& p0, hipStream_t s) {
     // equally long spans: the span length is chosen so that spans = waves x m for the smallest m that keeps a span at
     // <= 48 chunks (a span pays one pipeline fill; a wave that gets one span more than the others sets the kernel's time:
     // at config 4, 8-chunk spans round-robin left 6 or 7 spans per wave)
-    p.mfma_c = 3;                                             // (internal: tells pass_c_kernel to take the tail of a sorted list)
+    const bool det = p.det != 0;                              // (max aggregation never gets here)
+    p.mfma_c = det ? 4 : 3;                                   // (internal: 3 tells pass_c_kernel to take the tail of a sorted list,
+                                                              //  4 that the deterministic kernel takes it itself)
     const int64_t n_full = p.n_edges >> 6;
     int64_t blocks = (n_full + 3) / 4;
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
     const int64_t per_wave = (n_full + blocks * 4 - 1) / (blocks * 4), m = (per_wave + 47) / 48;
     const int span_c = span_env > 0 ? span_env : (int)((per_wave + (m > 0 ? m : 1) - 1) / (m > 0 ? m : 1));
-    if (p.lazy_e) hipLaunchKernelGGL(pass_c_sorted_kernel<true>, dim3((int)blocks), dim3(256), 0, s, p, span_c > 0 ? span_c : 1);
-    else hipLaunchKernelGGL(pass_c_sorted_kernel<false>, dim3((int)blocks), dim3(256), 0, s, p, span_c > 0 ? span_c : 1);
+    const int sc = span_c > 0 ? span_c : 1;
+    p.det_len = det ? sc * 64 : 32;
+    const dim3 grid((int)blocks);
+    if (det) {
+      if (p.lazy_e) hipLaunchKernelGGL((pass_c_sorted_kernel<true, true>), grid, dim3(256), 0, s, p, sc);
+      else hipLaunchKernelGGL((pass_c_sorted_kernel<false, true>), grid, dim3(256), 0, s, p, sc);
+    } else {
+      if (p.lazy_e) hipLaunchKernelGGL((pass_c_sorted_kernel<true, false>), grid, dim3(256), 0, s, p, sc);
+      else hipLaunchKernelGGL((pass_c_sorted_kernel<false, false>), grid, dim3(256), 0, s, p, sc);
+    }
   } else if (p.mfma_c) {
     // the any-order kernel.  Many edges (lists of >= 2^24 nodes, MTMC_PASS_C_GENERAL): short spans round-robin over a
     // resident grid; few edges: one 64-edge chunk per wave, as many waves as there are chunks

@@ -58,6 +58,7 @@ struct RoundParams {
   int lazy_e; const double* prev_stats;
   int mfma_c;                // set by launch_pass_c: the matrix-core pass C takes row-sorted lists
   int stream_z1;             // set by launch_pass_a: z1 is stored non-temporally (lists whose z1 outgrows the Infinity Cache)
+  int det_len;               // set by launch_pass_c: edges per carry chunk of the deterministic sums (32, or a span of the sorted kernel)
   int det; const int* flags; const int* deg; const int* row_start; float* carry; int64_t n_nodes;   // deterministic sums
   // edges per SOURCE ROW of this call's edges: local edges / owned rows for a row-complete shard, E_total / N otherwise
   // (a shard's local edge count over the GLOBAL node count would send 8 ranks of config 5 to the slow walk)

@@ -132,12 +132,13 @@ def test_training_order_rows_block_sorted_at_tracker_scale():
 
 
 def test_deterministic_mode_above_524288_edges(tracker):
-    """MTMC_F_DETERMINISTIC on a many-edge sorted list: per-chunk partials + agg_fixup_kernel instead of float atomics.
+    """MTMC_F_DETERMINISTIC on a many-edge sorted list: per-span partials + agg_fixup_kernel instead of float atomics, on the
+    matrix-core kernel (pass_c_sorted_kernel<., true>; E % 64 = 34: the partial last chunk is its own, too).
     h and the logits must be BITWISE equal between runs, and right."""
     m, sd, params = _model(3, 1)
     m = m.cuda()
     m.deterministic = True
-    assert engine.ForwardEngine(m).plan(1002, 751_202, flags=_lib.F_DETERMINISTIC).pass_c == _lib.PASS_C_WALK
+    assert engine.ForwardEngine(m).plan(1002, 751_202, flags=_lib.F_DETERMINISTIC).pass_c == _lib.PASS_C_MFMA_SORTED
     got1, h1 = _gpu(m, tracker)
     got2, h2 = _gpu(m, tracker)
     assert torch.equal(h1, h2) and torch.equal(got1[0], got2[0])
@@ -243,6 +244,30 @@ def _mixed_degree_graph(n_dense, pairs_dense, n_sparse, pairs_sparse, seed, drop
     x = torch.randn(n, 2048, generator=g)
     ea = torch.rand(ei.shape[1], 2, generator=g)
     return types.SimpleNamespace(x=x, edge_index=ei, edge_attr=ea)
+
+
+@pytest.mark.parametrize("tail", [0, 37])
+def test_deterministic_sorted_list_with_low_degree_stretches(tail):
+    """The same kind of list in deterministic mode: rows that span several spans, rows strictly inside one, groups of many
+    rows (all through masked passes there), a tail: bitwise repeatable, equal to the default mode within rounding, right."""
+    d = _mixed_degree_graph(1500, 270_000, 6000, 9_000, seed=78)
+    E = d.edge_index.shape[1]
+    drop = (E - tail) % 64
+    if drop:
+        d = types.SimpleNamespace(x=d.x, edge_index=d.edge_index[:, :E - drop].contiguous(), edge_attr=d.edge_attr[:E - drop].contiguous())
+    E = d.edge_index.shape[1]
+    m, sd, params = _model(2, 2)
+    m = m.cuda()
+    m.deterministic = True
+    assert engine.ForwardEngine(m).plan(d.x.shape[0], E, flags=_lib.F_DETERMINISTIC).pass_c == _lib.PASS_C_MFMA_SORTED
+    got1, h1 = _gpu(m, d, transposed_view=False)
+    got2, h2 = _gpu(m, d, transposed_view=False)
+    assert torch.equal(h1, h2) and all(torch.equal(a, b) for a, b in zip(got1, got2))
+    want64, h64 = _oracle(sd, params, d)
+    _check(got1, h1, want64, h64, f"deterministic, mixed degrees, E={E}")
+    m.deterministic = False
+    got3, h3 = _gpu(m, d, transposed_view=False)
+    assert (h3 - h1).abs().max().item() <= 1e-5 * max(1.0, h1.abs().max().item())
 
 
 @pytest.mark.parametrize("tail", [0, 1, 37])

@@ -61,7 +61,9 @@ def test_single_gpu_regimes(eng):
     cfg4 = eng.plan(100_000, 10_000_000)
     assert cfg4.enc_kernel[0] == _lib.GEMM_PRESPLIT_256 and cfg4.pass_c == _lib.PASS_C_MFMA_SORTED
     det = eng.plan(100_000, 10_000_000, flags=_lib.F_DETERMINISTIC)
-    assert det.pass_c == _lib.PASS_C_WALK               # fixed-order aggregation lives in the walk
+    assert det.pass_c == _lib.PASS_C_MFMA_SORTED        # many edges: the sorted kernel's fixed-order variant (no atomics)
+    det_small = eng.plan(450, 150_454, flags=_lib.F_DETERMINISTIC)
+    assert det_small.pass_c == _lib.PASS_C_WALK         # few edges: fixed-order aggregation lives in the walk
     trn = eng.plan(440, 180_000, training=True)
     assert trn.pass_c == _lib.PASS_C_WALK and not trn.lazy_edges     # Dropout in the node update; e' kept for the tape
 

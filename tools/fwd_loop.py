@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Plain forward loop on one workload (for rocprofv3 traces):  python tools/fwd_loop.py s02 [iters]"""
+"""Plain forward loop on one workload (for rocprofv3 traces):  python tools/fwd_loop.py s02 [iters]
+(MTMC_DETERMINISTIC=1: the module's fixed-order aggregation mode)"""
 import os
 import sys
 
@@ -18,6 +19,7 @@ _, L, cs = bench.WORKLOADS[name]
 params = mtmc_mpn.default_params(num_enc_steps=L, num_class_steps=cs)
 torch.manual_seed(0)
 model = mtmc_mpn.MOTMPNet(copy.deepcopy(params), None, "resnet101").to(dev).eval()
+model.deterministic = bool(os.environ.get("MTMC_DETERMINISTIC"))
 data = bench.make_workload(name, dev)
 sec, _ = bench.time_forward(model, data, iters, 10)
 print(f"{name}: {sec * 1e6:.1f} us/forward")
