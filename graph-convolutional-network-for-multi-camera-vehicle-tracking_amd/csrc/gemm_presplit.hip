@@ -96,24 +96,29 @@ void launch_split_rows(const float* X, int64_t ld, int64_t rows, int K, void* H,
 // the 16-byte slot l / 16 of its 64-byte image row (the stored swizzle makes every 16-lane group conflict-free here
 // too); plain two-stage loop, the compiler places the reads.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 1) void gemm_f16p_m16_kernel(SplitGemmParams p, int tiles_m, int tiles_n) {
+// The tile HEIGHT is a launch parameter (presplit_tile_rows): the first row of waves always takes 128 rows, the second
+// bm - 128 (a multiple of 16), and the two waves that share a SIMD are one of each -- with 256-row tiles the last round of
+// workgroups of config 4 (1564 tiles = 6.11 rounds on 256 CUs) ran on a tenth of the chip.
+__global__ __launch_bounds__(512, 1) void gemm_f16p_m16_kernel(SplitGemmParams p, int tiles_m, int tiles_n, int bm) {
   constexpr int BT = 256, BK = 32, NT = 512, ROWB = BK * 2, IMG = BT * ROWB, STAGE = 4 * IMG;
   constexpr int SLOTS = BK / 8, RPI = NT / SLOTS, IPI = BT / RPI;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int tm_idx = (slot / tiles_n) * 8 + xcd, tn_idx = slot % tiles_n;
   if (tm_idx >= tiles_m) return;
-  const int64_t m0 = (int64_t)tm_idx * BT;
+  const int64_t m0 = (int64_t)tm_idx * bm;
   const int n0 = tn_idx * BT;
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wid / 4, wn = wid % 4;
+  const int nblk = wm == 0 ? 8 : (bm - 128) / 16;                  // 16-row blocks of this wave
+  const int64_t m_end = m0 + bm < p.M ? m0 + bm : p.M;             // rows of this tile: [m0, m_end)
 
   const int r0 = threadIdx.x / SLOTS, sp = threadIdx.x % SLOTS;
   unsigned off_a[IPI], off_w[IPI];
 #pragma unroll
   for (int j = 0; j < IPI; ++j) {
     const int r = r0 + RPI * j;
-    const int64_t ar = m0 + r < p.M ? r : p.M - 1 - m0;
+    const int64_t ar = m0 + r < m_end ? r : m_end - 1 - m0;       // (rows past the tile: a valid row again, never used)
     const int br = n0 + r < p.Nout ? r : p.Nout - 1 - n0;
     off_a[j] = (unsigned)(ar * BK + sp * 8) * 2u;
     off_w[j] = (unsigned)(br * BK + sp * 8) * 2u;
@@ -129,7 +134,11 @@ __global__ __launch_bounds__(512, 1) void gemm_f16p_m16_kernel(SplitGemmParams p
     for (int im = 0; im < 4; ++im) {
       const char* sb = (im < 2 ? a_tile : w_tile) + (im & 1 ? (im < 2 ? a_plane : w_plane) : 0) + kt * (im < 2 ? a_kt : w_kt);
 #pragma unroll
-      for (int j = 0; j < IPI; ++j) lds_dma16(sb, im < 2 ? off_a[j] : off_w[j], st + im * IMG + j * (NT * 16));
+      for (int j = 0; j < IPI; ++j) {
+        // (A rows 128 + 16 wid .. + 15 of the second pass lie past a shorter tile's height: wave-uniform skip)
+        if (im < 2 && j == 1 && 128 + wid * 16 >= bm) continue;
+        lds_dma16(sb, im < 2 ? off_a[j] : off_w[j], st + im * IMG + j * (NT * 16));
+      }
     }
   };
 
@@ -155,6 +164,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16p_m16_kernel(SplitGemmParams p
       f16x8 a[2];
 #pragma unroll
       for (int q = 0; q < 2; ++q) a[q] = *reinterpret_cast<const f16x8*>(st + q * IMG + a_row + i * 16 * ROWB);
+      if (i < nblk) {                                      // (blocks past the tile's height: wave-uniform skip)
       // the three products of a block go out back to back: the second and third take the accumulator the first just
       // produced (1.072 ms against 1.101 ms for runs of four MFMAs on four different accumulators, same box: the chained
       // form draws less power, and at the power cap that is time)
@@ -164,6 +174,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16p_m16_kernel(SplitGemmParams p
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[j][0], acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[j][1], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+      }
       }
     }
   };
@@ -200,6 +211,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16p_m16_kernel(SplitGemmParams p
   const int gcol = n0 + wn * 64 + rcol;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
+    if (i < nblk) {                                       // (no `break`: the loop must unroll, acc[] is registers)
     const int64_t row0 = m0 + wm * 128 + i * 16;
     float ia[4];
 #pragma unroll
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16p_m16_kernel(SplitGemmParams p
       for (int r = 0; r < 4; ++r) {
         const float y = fmaf(acc[i][j][r] * ia[r], iw[j], bias[j]);
         stg[(4 * ks + r) * kStgLd + j * 16 + r16] = y;
-        if (row0 + 4 * ks + r < p.M && cok) {
+        if (row0 + 4 * ks + r < m_end && cok) {
           ymax = fmaxf(ymax, fabsf(y));
           cs[j] += y;
           cq[j] += (double)y * y;
@@ -226,7 +238,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16p_m16_kernel(SplitGemmParams p
       const int rr = rrow + 4 * q;
       const int64_t row = row0 + rr;
       const float4 v = *reinterpret_cast<const float4*>(stg + rr * kStgLd + rcol);
-      if (row < p.M) {
+      if (row < m_end) {
         float* dst = p.Y + row * p.ldy + gcol;
         if (vec_ok && gcol + 3 < p.Nout) {
           *reinterpret_cast<float4*>(dst) = v;
@@ -241,6 +253,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16p_m16_kernel(SplitGemmParams p
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -283,13 +296,31 @@ bool presplit_layer0(int64_t rows, int K, int Nout) {
   return !off && K % 64 == 0 && K <= 2048 && rows >= 4096 && gemm_plan(rows, K, Nout, &sk) == 2;
 }
 
+// Tile height: 144 .. 256 rows in steps of 16; the one that minimises rounds of workgroups x height (+ a tile's fixed
+// cost in row equivalents).  Config 4: 224 rows, 1788 tiles = 6.98 rounds of 7/8 of the work each, instead of 1564 tiles =
+// 6.11 rounds paid as 7.
+int presplit_tile_rows(int64_t M, int tiles_n) {
+  const int forced = knobs().presplit_rows;
+  if (forced >= 144 && forced <= 256 && forced % 16 == 0) return forced;
+  int best = 256;
+  int64_t best_cost = -1;
+  for (int bm = 256; bm >= 144; bm -= 16) {
+    const int64_t tiles = (M + bm - 1) / bm * tiles_n, rounds = (tiles + 255) / 256;
+    const int64_t cost = rounds * (bm + 8);
+    if (best_cost < 0 || cost < best_cost) { best = bm; best_cost = cost; }
+  }
+  return best;
+}
+
 int launch_gemm_presplit(const SplitGemmParams& p, hipStream_t s) {
   if (p.K % 64 || p.K > 2048 || p.M < 1 || p.Nout < 1) return 1;
-  const int tiles_m = (int)((p.M + 255) / 256), tiles_n = (p.Nout + 255) / 256;
+  const int tiles_n = (p.Nout + 255) / 256;
+  const int bm = presplit_tile_rows(p.M, tiles_n);
+  const int tiles_m = (int)((p.M + bm - 1) / bm);
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
   const size_t lds = (size_t)2 * 4 * 256 * 32 * 2;
   if (!allow_big_lds(reinterpret_cast<const void*>(gemm_f16p_m16_kernel), 160 * 1024)) return MTMC_E_HIP;
-  hipLaunchKernelGGL(gemm_f16p_m16_kernel, dim3(grid), dim3(512), lds, s, p, tiles_m, tiles_n);
+  hipLaunchKernelGGL(gemm_f16p_m16_kernel, dim3(grid), dim3(512), lds, s, p, tiles_m, tiles_n, bm);
   return MTMC_OK;
 }
 

@@ -51,6 +51,29 @@ def test_presplit_matches_float64(shape, variant):
     assert torch.allclose(st[N:], (Y.double() ** 2).sum(0), rtol=1e-9)
 
 
+@pytest.mark.parametrize("M", [45_000, 60_000, 70_001, 100_000])
+def test_presplit_tile_heights(M):
+    """The product kernel picks its tile height per launch (presplit_tile_rows: 144 .. 256 rows, the one that fills the last
+    round of workgroups): 176, 240, 224 and 224 rows for these row counts at four column tiles, ragged last tiles included."""
+    from mtmc_mpn import _lib
+    lib = _lib.load()
+    K, N = 64, 1024
+    g = torch.Generator(device="cuda").manual_seed(M)
+    A = torch.randn(M, K, device="cuda", generator=g) * torch.exp(2 * torch.randn(M, 1, device="cuda", generator=g))
+    W = (torch.rand(N, K, device="cuda", generator=g) * 2 - 1) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    Y, st, ymax, _ = _run(lib, A, W, b, "product")
+    ref = A.double() @ W.double().t() + b.double()
+    bound = A.double().abs() @ W.double().abs().t() + b.double().abs()
+    assert torch.isfinite(Y).all()
+    # 64 terms do not average: the budget is the worst case of two truncated two-piece operands (2^-20 each), as for the
+    # short-K cases of tests/test_gpu_gemm_staged.py; the statistical 3e-7 of the other tests holds from K = 512 on
+    assert ((Y.double() - ref).abs() / bound).max().item() < 2.0 ** -19
+    assert ymax == Y.abs().max().item()
+    assert torch.allclose(st[:N], Y.double().sum(0), rtol=1e-9, atol=1e-9 * Y.abs().max().item() * M)
+    assert torch.allclose(st[N:], (Y.double() ** 2).sum(0), rtol=1e-9)
+
+
 def test_presplit_strided_rows_and_reused_planes():
     from mtmc_mpn import _lib
     lib = _lib.load()
