@@ -296,7 +296,7 @@ bool presplit_layer0(int64_t rows, int K, int Nout) {
   return !off && K % 64 == 0 && K <= 2048 && rows >= 4096 && gemm_plan(rows, K, Nout, &sk) == 2;
 }
 
-// Tile height: 144 .. 256 rows in steps of 16; the one that minimises rounds of workgroups x height (+ a tile's fixed
+// Tile height: 144 .. 256 rows in steps of 16; the one that minimises rounds of workgroups x (height + a tile's fixed
 // cost in row equivalents).  Config 4: 224 rows, 1788 tiles = 6.98 rounds of 7/8 of the work each, instead of 1564 tiles =
 // 6.11 rounds paid as 7.
 int presplit_tile_rows(int64_t M, int tiles_n) {
@@ -306,7 +306,9 @@ int presplit_tile_rows(int64_t M, int tiles_n) {
   int64_t best_cost = -1;
   for (int bm = 256; bm >= 144; bm -= 16) {
     const int64_t tiles = (M + bm - 1) / bm * tiles_n, rounds = (tiles + 255) / 256;
-    const int64_t cost = rounds * (bm + 8);
+    // + 36: a tile's fixed cost in row equivalents (its W operand, prologue, epilogue), fitted to config 5 on one box:
+    // 256 / 240 / 224 rows = 62 / 66 / 70 rounds took 10474 / 10452 / 10527 us
+    const int64_t cost = rounds * (bm + 36);
     if (best_cost < 0 || cost < best_cost) { best = bm; best_cost = cost; }
   }
   return best;

@@ -51,10 +51,11 @@ def test_presplit_matches_float64(shape, variant):
     assert torch.allclose(st[N:], (Y.double() ** 2).sum(0), rtol=1e-9)
 
 
-@pytest.mark.parametrize("M", [45_000, 60_000, 70_001, 100_000])
+@pytest.mark.parametrize("M", [4_100, 20_000, 45_000, 70_001, 100_000])
 def test_presplit_tile_heights(M):
     """The product kernel picks its tile height per launch (presplit_tile_rows: 144 .. 256 rows, the one that fills the last
-    round of workgroups): 176, 240, 224 and 224 rows for these row counts at four column tiles, ragged last tiles included."""
+    round of workgroups): 144, 160, 240, 224 and 224 rows for these row counts at four column tiles, ragged last tiles
+    included."""
     from mtmc_mpn import _lib
     lib = _lib.load()
     K, N = 64, 1024
