@@ -440,12 +440,16 @@ bool staged_layer(int64_t rows, int K, int Nout) {
 // 80..128 step 16 for wm = 2, 160..256 step 32 for wm = 4.  Take the one that minimises rounds x height: 112 rows for that
 // layer 1 (1786 tiles = 6.98 rounds of 7/8 of the work each), 224 for its layer 2 (447 tiles, two rounds).
 int staged_tile_rows(int64_t M, int tiles_n, int wm) {
+  const int forced = knobs().staged_xr;                   // MTMC_STAGED_XR: rows of the second half of the consumer waves
+  if (forced >= 16 && forced <= 64 && forced % 16 == 0) return 32 * wm + (wm / 2) * forced;
   int best = 64 * wm;
   int64_t best_cost = -1;
   for (int xr = 64; xr >= 16; xr -= 16) {
     const int bm = 32 * wm + (wm / 2) * xr;
     const int64_t tiles = (M + bm - 1) / bm * tiles_n, rounds = (tiles + 255) / 256;
-    const int64_t cost = rounds * (bm + 4 * wm);         // + 4 wm: a tile's fixed cost (prologue, epilogue) in row equivalents
+    // + 12 wm: a tile's fixed cost (its W stream, prologue, epilogue) in row equivalents, fitted on one box (MTMC_STAGED_XR):
+    // layer 1 at 1M / 125k / 100k rows took 4.17 / 0.603 / 0.508 ms with 128-row tiles and 4.24 / 0.621 / 0.496 with 112
+    const int64_t cost = rounds * (bm + 12 * wm);
     if (best_cost < 0 || cost < best_cost) { best = bm; best_cost = cost; }
   }
   return best;

@@ -10,6 +10,7 @@ namespace mtmc {
 struct Knobs {
   bool pass_c_walk;          // MTMC_PASS_C_WALK: pass C on the half-wave walk everywhere
   int64_t pass_c_small_min;  // MTMC_PASS_C_SMALL_MIN: fewest edges for the matrix-core pass C on few-edge lists
+  int staged_xr;             // MTMC_STAGED_XR: rows (16..64) of the shorter consumer waves of the role-split GEMM (0 = per launch)
   int presplit_rows;         // MTMC_PRESPLIT_ROWS: tile height of the layer-0 GEMM (0 = chosen per launch)
   bool pass_c_general;       // MTMC_PASS_C_GENERAL: many-edge sorted lists on the any-order matrix-core kernel (A/B)
   int pass_c_span;           // MTMC_PASS_C_SPAN: 64-edge chunks per wave span (0 = default)

@@ -12,6 +12,7 @@ static Knobs read_knobs() {
   auto num = [](const char* name, long long dflt) { const char* v = getenv(name); return v ? atoll(v) : dflt; };
   k.pass_c_walk = on("MTMC_PASS_C_WALK");
   k.pass_c_small_min = num("MTMC_PASS_C_SMALL_MIN", 32768);
+  k.staged_xr = (int)num("MTMC_STAGED_XR", 0);
   k.presplit_rows = (int)num("MTMC_PRESPLIT_ROWS", 0);
   k.pass_c_general = on("MTMC_PASS_C_GENERAL");
   k.pass_c_span = (int)num("MTMC_PASS_C_SPAN", 0);
