@@ -26,20 +26,30 @@ class Layer(C.Structure):
 
 
 class Model(C.Structure):
-    _fields_ = [("n_enc_layers", C.c_int32), ("enc_node", Layer * MAX_ENC_LAYERS), ("enc_edge", Layer * 2),
+    """mtmc_mpn_model.  struct_bytes (ABI v5) is filled in on construction: the library refuses any other size."""
+    _fields_ = [("struct_bytes", C.c_uint32), ("n_enc_layers", C.c_int32), ("enc_node", Layer * MAX_ENC_LAYERS), ("enc_edge", Layer * 2),
                 ("upd_edge", Layer), ("upd_node", Layer), ("cls", Layer),
                 ("agg", C.c_int32), ("num_enc_steps", C.c_int32), ("num_class_steps", C.c_int32),
                 ("reattach_nodes", C.c_int32), ("reattach_edges", C.c_int32),
                 ("dropout_enc", C.c_float), ("dropout_upd_edge", C.c_float), ("dropout_upd_node", C.c_float)]
 
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_bytes = C.sizeof(type(self))
+
 
 class Call(C.Structure):
-    _fields_ = [("x", C.c_void_p), ("x_row_stride", C.c_int64), ("row", C.c_void_p), ("col", C.c_void_p),
+    """mtmc_mpn_call.  struct_bytes is filled in on construction, as in Model."""
+    _fields_ = [("struct_bytes", C.c_uint32), ("x", C.c_void_p), ("x_row_stride", C.c_int64), ("row", C.c_void_p), ("col", C.c_void_p),
                 ("idx_stride", C.c_int64), ("edge_attr", C.c_void_p), ("n_nodes", C.c_int64), ("n_edges", C.c_int64),
                 ("n_edges_total", C.c_int64), ("node_lo", C.c_int64), ("node_hi", C.c_int64),
                 ("logits", C.c_void_p), ("h_out", C.c_void_p), ("workspace", C.c_void_p),
                 ("workspace_bytes", C.c_size_t), ("training", C.c_int32), ("flags", C.c_int32),
                 ("seed", C.c_uint64), ("stream", C.c_void_p), ("row_lo", C.c_int64), ("row_hi", C.c_int64)]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_bytes = C.sizeof(type(self))
 
 
 class WsLayout(C.Structure):
@@ -159,7 +169,7 @@ def load() -> C.CDLL:
     lib.mtmc_mlp_layer_forward.restype = C.c_int32
     lib.mtmc_mlp_layer_forward.argtypes = [C.POINTER(Layer), C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                            C.c_void_p]
-    if lib.mtmc_mpn_abi_version() != 4:
+    if lib.mtmc_mpn_abi_version() != 5:
         raise RuntimeError("mtmc_mpn: ABI version mismatch between _lib.py and libmtmc_mpn.so")
     _lib = lib
     return lib

@@ -67,7 +67,8 @@ int32_t mtmc_mpn_run_phase(const mtmc_mpn_model* model, const mtmc_mpn_call* cal
 
 int32_t mtmc_mpn_plan_call(const mtmc_mpn_model* model, const mtmc_mpn_call* call, mtmc_mpn_plan* out) {
   if (int rc = check_model(model)) return rc;
-  if (!call || !out) return fail(MTMC_E_ARG, "mtmc_mpn_plan_call: NULL call or result");
+  if (!out) return fail(MTMC_E_ARG, "mtmc_mpn_plan_call: NULL result");
+  if (int rc = check_call_size(call)) return rc;
   const mtmc_mpn_call* c = call;
   if (c->n_nodes < 0 || c->n_edges < 0 || c->n_edges > c->n_edges_total || c->node_lo < 0 || c->node_hi < c->node_lo ||
       c->node_hi > c->n_nodes || c->row_lo < 0 || c->row_hi < c->row_lo || c->row_hi > c->n_nodes)

@@ -51,6 +51,9 @@ constexpr int kBwdStride = 256;                // doubles per replica of the bac
 
 inline int check_model(const mtmc_mpn_model* m) {
   if (!m) return fail(MTMC_E_ARG, "model is NULL");
+  if (m->struct_bytes != sizeof(mtmc_mpn_model))
+    return fail(MTMC_E_ARG, "mtmc_mpn_model.struct_bytes is %u, this library's struct has %zu bytes (ABI v%d): rebuild the caller against include/mtmc_mpn.h",
+                m->struct_bytes, sizeof(mtmc_mpn_model), MTMC_MPN_ABI_VERSION);
   if (m->n_enc_layers < 1 || m->n_enc_layers > MTMC_MAX_ENC_LAYERS) return fail(MTMC_E_ARG, "n_enc_layers out of range");
   for (int l = 0; l < m->n_enc_layers; ++l) {
     const mtmc_layer& L = m->enc_node[l];
@@ -188,9 +191,18 @@ struct Ctx {
   template <typename T> T* at(size_t off) const { return reinterpret_cast<T*>(ws + off); }
 };
 
+// the size guard of the call struct (ABI v5): a caller built against an older, shorter struct is refused, not read past
+inline int check_call_size(const mtmc_mpn_call* c) {
+  if (!c) return fail(MTMC_E_ARG, "call is NULL");
+  if (c->struct_bytes != sizeof(mtmc_mpn_call))
+    return fail(MTMC_E_ARG, "mtmc_mpn_call.struct_bytes is %u, this library's struct has %zu bytes (ABI v%d): rebuild the caller against include/mtmc_mpn.h",
+                c->struct_bytes, sizeof(mtmc_mpn_call), MTMC_MPN_ABI_VERSION);
+  return MTMC_OK;
+}
+
 inline int make_ctx(const mtmc_mpn_model* m, const mtmc_mpn_call* c, Ctx* ctx) {
   if (int rc = check_model(m)) return rc;
-  if (!c) return fail(MTMC_E_ARG, "call is NULL");
+  if (int rc = check_call_size(c)) return rc;
   if (c->training && (c->node_lo != 0 || c->node_hi != c->n_nodes || c->n_edges_total != c->n_edges))
     return fail(MTMC_E_ARG, "training mode is single-shard only");
   if (c->n_nodes < 2) return fail(MTMC_E_ROWS, "BatchNorm over %lld node rows: Expected more than 1 value per channel", (long long)c->n_nodes);

@@ -15,6 +15,7 @@ namespace {
 
 int check_grads(const mtmc_mpn_model* m, const mtmc_mpn_model* g) {
   if (!g) return fail(MTMC_E_ARG, "grads is NULL");
+  if (g->struct_bytes != sizeof(mtmc_mpn_model)) return fail(MTMC_E_ARG, "grads.struct_bytes is %u, expected %zu", g->struct_bytes, sizeof(mtmc_mpn_model));
   for (int l = 0; l < m->n_enc_layers; ++l)
     if (!g->enc_node[l].weight || !g->enc_node[l].bias || !g->enc_node[l].gamma || !g->enc_node[l].beta)
       return fail(MTMC_E_ARG, "grads: NULL node-encoder gradient buffer");
@@ -223,7 +224,9 @@ extern "C" int32_t mtmc_mpn_backward(const mtmc_mpn_model* model, const mtmc_mpn
                                      const float* d_h, const mtmc_mpn_model* grads, float* d_x, float* d_edge_attr) {
   const float* steps[64];
   int n_out = 0;
-  if (model && call && d_logits) {
+  if (int rc = check_model(model)) return rc;          // (incl. the struct-size guards, before any field is trusted)
+  if (int rc = check_call_size(call)) return rc;
+  if (d_logits) {
     n_out = model->num_enc_steps > 0 ? std::min(model->num_class_steps, model->num_enc_steps) : 1;
     if (n_out > 64) return fail(MTMC_E_ARG, "more than 64 classified steps");
     for (int i = 0; i < n_out; ++i) steps[i] = d_logits + (size_t)i * call->n_edges * model->cls.out_dim;
@@ -244,7 +247,8 @@ extern "C" int32_t mtmc_mpn_backward_steps(const mtmc_mpn_model* model, const mt
 // and views it with the same rule (mtmc_mpn_grad_layout: offsets in floats, returns the total), instead of filling a
 // second 34-pointer struct per call.
 extern "C" int64_t mtmc_mpn_grad_layout(const mtmc_mpn_model* m, int64_t* offsets, int32_t max_offsets) {
-  if (!m || m->n_enc_layers < 1 || m->n_enc_layers > MTMC_MAX_ENC_LAYERS) return 0;   // (0 = no layout: bad model)
+  if (!m || m->struct_bytes != sizeof(mtmc_mpn_model) || m->n_enc_layers < 1 || m->n_enc_layers > MTMC_MAX_ENC_LAYERS)
+    return 0;                                                                           // (0 = no layout: bad model)
   int64_t total = 0;
   int n = 0;
   auto piece = [&](int64_t numel) {

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MTMC_MPN_ABI_VERSION 4
+#define MTMC_MPN_ABI_VERSION 5
 
 #define MTMC_MAX_ENC_LAYERS 8   /* hidden layers of the node encoder MLP          */
 #define MTMC_NODE_DIM 32        /* H : width of the node state the kernels are built for */
@@ -69,6 +69,10 @@ typedef struct mtmc_layer {
 
 /* The 34 parameter tensors of the reference model + its structural flags. */
 typedef struct mtmc_mpn_model {
+  uint32_t struct_bytes;                        /* = sizeof(mtmc_mpn_model) of the header the CALLER was compiled against;
+                                                   every entry point returns MTMC_E_ARG unless it equals the library's
+                                                   (a binding written for an older, shorter struct fails loudly instead
+                                                   of being read past its end) */
   int32_t n_enc_layers;                         /* node encoder: 2048->1024->512->128->32 => 4 */
   mtmc_layer enc_node[MTMC_MAX_ENC_LAYERS];     /* encoder.node_mlp.fc_layers.{0,4,8,12}(+1)   */
   mtmc_layer enc_edge[2];                       /* encoder.edge_mlp: in(1|2)->4->4              */
@@ -87,6 +91,7 @@ typedef struct mtmc_mpn_model {
 
 /* One forward call.  For a single GPU: node_lo=0, node_hi=n_nodes, n_edges_total=n_edges. */
 typedef struct mtmc_mpn_call {
+  uint32_t struct_bytes;     /* = sizeof(mtmc_mpn_call), checked like mtmc_mpn_model::struct_bytes */
   const float* x;            /* [node_hi-node_lo, F] rows node_lo.. of data.x           */
   int64_t x_row_stride;      /* elements between consecutive rows of x                  */
   const int64_t* row;        /* data.edge_index[0]: element e at row[e*idx_stride]      */

@@ -46,6 +46,7 @@ int main(int argc, char** argv) {
 
   const int dims[5] = {(int)F, 1024, 512, 128, 32};
   mtmc_mpn_model m = {};
+  m.struct_bytes = sizeof(m);
   int k = 0;
   m.n_enc_layers = 4;
   auto layer = [&](mtmc_layer& l, int in, int out, bool bn) {
@@ -73,6 +74,7 @@ int main(int argc, char** argv) {
   CHECK(hipMalloc(&d_h, N * 32 * 4));
   CHECK(hipMalloc(&ws, ws_bytes));
   mtmc_mpn_call c = {};
+  c.struct_bytes = sizeof(c);
   c.x = d_x; c.x_row_stride = F; c.row = d_ei; c.col = d_ei + E; c.idx_stride = 1; c.edge_attr = d_attr;
   c.n_nodes = N; c.n_edges = E; c.n_edges_total = E; c.node_lo = 0; c.node_hi = N;
   c.logits = d_logits; c.h_out = d_h; c.workspace = ws; c.workspace_bytes = ws_bytes; c.stream = nullptr;

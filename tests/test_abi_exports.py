@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     assert set(_lib.EXPORTS) <= declared
     lib.mtmc_mpn_abi_version.restype = ctypes.c_int32
-    assert lib.mtmc_mpn_abi_version() == 4
+    assert lib.mtmc_mpn_abi_version() == 5
 
 
 def test_workspace_sizing_needs_no_gpu():
@@ -42,6 +42,53 @@ def test_workspace_sizing_needs_no_gpu():
     lay = _lib.WsLayout()
     assert lib.mtmc_mpn_workspace_layout(ctypes.byref(model), 450, 150454, ctypes.byref(lay)) == 0
     assert lay.total_bytes == small and lay.zero_bytes < lay.h0_off
+
+
+def test_struct_size_guard_refuses_older_callers():
+    """ABI v5: a caller compiled against a shorter (older) struct is refused with MTMC_E_ARG instead of being read past
+    its end -- checked on the host-only entry points (size queries, plan), which share check_model / check_call_size
+    with mtmc_mpn_forward / _run_phase / _backward*."""
+    import mtmc_mpn
+    from mtmc_mpn import _lib, engine
+    m = mtmc_mpn.MOTMPNet(mtmc_mpn.default_params(num_enc_steps=3), None, "resnet101")
+    lib = _lib.load()
+    eng = engine.ForwardEngine(m)
+    model = eng.model_struct(next(m.parameters()).device)
+    assert model.struct_bytes == ctypes.sizeof(_lib.Model) and _lib.Call().struct_bytes == ctypes.sizeof(_lib.Call)
+    call = _lib.Call()
+    call.n_nodes, call.n_edges, call.n_edges_total, call.node_hi = 450, 150454, 150454, 450
+    plan = _lib.Plan()
+    assert lib.mtmc_mpn_plan_call(ctypes.byref(model), ctypes.byref(call), ctypes.byref(plan)) == 0
+    # the ABI-v3 call struct ended at `stream`: 16 bytes shorter
+    call.struct_bytes = ctypes.sizeof(_lib.Call) - 16
+    assert lib.mtmc_mpn_plan_call(ctypes.byref(model), ctypes.byref(call), ctypes.byref(plan)) == _lib.E_ARG
+    assert b"struct_bytes" in lib.mtmc_mpn_last_error()
+    call.struct_bytes = 0                                # a caller that never heard of the field
+    assert lib.mtmc_mpn_plan_call(ctypes.byref(model), ctypes.byref(call), ctypes.byref(plan)) == _lib.E_ARG
+    assert lib.mtmc_mpn_run_phase(ctypes.byref(model), ctypes.byref(call), _lib.PH_BEGIN, 0) == _lib.E_ARG
+    assert lib.mtmc_mpn_forward(ctypes.byref(model), ctypes.byref(call)) == _lib.E_ARG      # refused before any launch
+    call.struct_bytes = ctypes.sizeof(_lib.Call)
+    model.struct_bytes -= 8
+    assert lib.mtmc_mpn_workspace_bytes(ctypes.byref(model), 450, 150454) == 0
+    assert lib.mtmc_mpn_plan_call(ctypes.byref(model), ctypes.byref(call), ctypes.byref(plan)) == _lib.E_ARG
+    assert lib.mtmc_mpn_grad_layout(ctypes.byref(model), None, 0) == 0
+
+
+def test_struct_sizes_match_the_header(tmp_path):
+    """sizeof() of the two call structs as gcc lays them out == the ctypes mirrors in _lib.py."""
+    import shutil
+    import subprocess
+    from mtmc_mpn import _lib
+    if shutil.which("gcc") is None:
+        import pytest
+        pytest.skip("no gcc")
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "mtmc_mpn.h"\nint main(void) { printf("%zu %zu %zu %zu\\n", '
+                   'sizeof(mtmc_mpn_model), sizeof(mtmc_mpn_call), sizeof(mtmc_ws_layout), sizeof(mtmc_mpn_plan)); return 0; }\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert got == [ctypes.sizeof(_lib.Model), ctypes.sizeof(_lib.Call), ctypes.sizeof(_lib.WsLayout), ctypes.sizeof(_lib.Plan)]
 
 
 def test_header_is_plain_c(tmp_path):
