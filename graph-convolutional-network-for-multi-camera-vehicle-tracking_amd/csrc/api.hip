@@ -93,7 +93,10 @@ int32_t mtmc_mpn_plan_call(const mtmc_mpn_model* model, const mtmc_mpn_call* cal
   out->lazy_edges = lazy_edges(c) ? 1 : 0;
   out->avg_degree = avg_degree(c);
   const bool drop_n = c->training && model->dropout_upd_node > 0.f;
-  out->pass_c = mtmc::plan_pass_c(model->agg, (c->flags & MTMC_F_DETERMINISTIC) != 0, drop_n, c->n_edges, out->avg_degree);
+  // the public enum names what launch_pass_c launches: the sorted kernel is MFMA_SORTED, the any-order kernel MFMA_ANY
+  // (on a many-edge list it still has the walk launched behind it for unsorted rows)
+  const int pc = mtmc::plan_pass_c(model->agg, (c->flags & MTMC_F_DETERMINISTIC) != 0, drop_n, c->n_edges, c->n_nodes, out->avg_degree);
+  out->pass_c = pc == 1 ? (mtmc::pass_c_sorted_taken(c->n_nodes) ? MTMC_PASS_C_MFMA_SORTED : MTMC_PASS_C_MFMA_ANY) : pc;
   return MTMC_OK;
 }
 

@@ -1257,6 +1257,7 @@ static inline int edge_grid(int64_t n_edges, int per_block) {
 // Below this many edges a pass at 4 edges/thread would leave most of the 256 CUs with one or two waves: use the
 // finest decomposition there (measured on camera graphs of 50k..12M edges, tools/size_sweep.py).
 constexpr int64_t kSmallEdges = 2048 * 256;
+constexpr int64_t kSortedMaxNodes = 1ll << 24;   // pass_c_sorted_kernel keeps row ids in 24 bits
 static inline int pick_ept(int64_t n_edges) { return n_edges <= kSmallEdges ? 1 : 4; }
 #ifndef MTMC_PASS_A_EPT
 #define MTMC_PASS_A_EPT 4
@@ -1317,21 +1318,26 @@ void launch_pass_b(const RoundParams& p, hipStream_t s) {
 // on the device).  mfma_c = 2 (few-edge lists, where a second launch would cost as much as the pass): the matrix-core
 // kernel alone, whatever the order -- it is correct for any order, groups that touch many rows just take one masked pass
 // per row.  MTMC_PASS_C_WALK=1 keeps the walk everywhere (A/B).
-int plan_pass_c(int agg, bool deterministic, bool dropout, int64_t n_edges, double avg_degree) {
+int plan_pass_c(int agg, bool deterministic, bool dropout, int64_t n_edges, int64_t n_nodes, double avg_degree) {
   const Knobs& kn = knobs();
   if (kn.pass_c_walk || agg == 2 || dropout || avg_degree < 24.0) return 0;
-  if (n_edges > kSmallEdges) return (deterministic && kn.pass_c_general) ? 0 : 1;   // (sorted kernel: also in deterministic mode)
+  // many-edge lists: the sorted kernel (also in deterministic mode) -- unless the call gets the any-order kernel instead
+  // (MTMC_PASS_C_GENERAL, or >= 2^24 GLOBAL node rows, reachable with row-sharded multi-GPU calls): that one only knows
+  // float atomics, so a deterministic call keeps the walk there (its carry[] is what agg_fixup_kernel adds up)
+  if (n_edges > kSmallEdges) return (deterministic && (kn.pass_c_general || n_nodes >= kSortedMaxNodes)) ? 0 : 1;
   if (deterministic) return 0;                               // few edges: fixed-order sums live in the walk
   return n_edges >= kn.pass_c_small_min ? 2 : 0;
 }
 int plan_edges_per_thread(int64_t n_edges) { return pick_ept(n_edges); }
+// plan value 1 (many-edge list): pass_c_sorted_kernel, or the any-order matrix-core kernel + the walk behind it
+bool pass_c_sorted_taken(int64_t n_nodes) { return !knobs().pass_c_general && n_nodes < kSortedMaxNodes; }
 
 void launch_pass_c(const RoundParams& p0, hipStream_t s) {
   RoundParams p = p0;
   p.det_len = 32;
-  p.mfma_c = plan_pass_c(p.agg, p.det != 0, p.drop_n.on != 0, p.n_edges, p.avg_degree);
+  p.mfma_c = plan_pass_c(p.agg, p.det != 0, p.drop_n.on != 0, p.n_edges, p.n_nodes, p.avg_degree);
   const int span_env = knobs().pass_c_span, max_blocks = knobs().pass_c_blocks;
-  if (p.mfma_c == 1 && !knobs().pass_c_general && p.n_nodes < (1ll << 24)) {
+  if (p.mfma_c == 1 && pass_c_sorted_taken(p.n_nodes)) {
     // many-edge sorted lists: a grid of twice what is resident (104 registers: four blocks per CU; the block prologue -- 74 replicated
     // statistics, one BatchNorm affine per channel -- is paid once per block) whose waves all take the same number of
     // equally long spans: the span length is chosen so that spans = waves x m for the smallest m that keeps a span at

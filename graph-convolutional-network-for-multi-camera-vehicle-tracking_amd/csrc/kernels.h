@@ -157,7 +157,8 @@ void launch_pass_c(const RoundParams& p, hipStream_t s);
 // Which pass-C kernel a call takes (host-only decision, also behind mtmc_mpn_plan): 0 = the half-wave walk; 1 = the
 // matrix-core kernel with the walk launched behind it for unsorted rows (many-edge lists); 2 = the matrix-core kernel
 // alone (few-edge lists).  avg_degree: edges per source row of THIS call's edges (RoundParams::avg_degree).
-int plan_pass_c(int agg, bool deterministic, bool dropout, int64_t n_edges, double avg_degree);
+int plan_pass_c(int agg, bool deterministic, bool dropout, int64_t n_edges, int64_t n_nodes, double avg_degree);
+bool pass_c_sorted_taken(int64_t n_nodes);
 int plan_edges_per_thread(int64_t n_edges);      // passes A / B: 1 on few-edge lists, 4 otherwise
 void launch_classify_e0(const EdgeEncParams& enc, const float* attr, int64_t n_edges, double e_total,
                         const float* cls_w, const float* cls_b, int n_classes, float* logits, hipStream_t s);

@@ -213,8 +213,10 @@ typedef struct mtmc_mpn_plan {
   int32_t enc_split_k[MTMC_MAX_ENC_LAYERS];  /* K slices (few-row layers; > 1 => MTMC_PH_NODE_COMBINE does work)    */
   int32_t edges_per_thread;                  /* passes A / B                                                        */
   int32_t lazy_edges;                        /* 1: e' is never stored, consumers recompute it from z1               */
-  int32_t pass_c;                            /* MTMC_PASS_C_*: half-wave walk / matrix-core kernel + the walk launched
-                                                behind it for unsorted rows / matrix-core kernel alone               */
+  int32_t pass_c;                            /* MTMC_PASS_C_*: half-wave walk / pass_c_sorted_kernel (many-edge lists; it
+                                                returns at once on unsorted rows and the walk behind it does the round) /
+                                                the any-order matrix-core kernel (few-edge lists: alone; many-edge lists
+                                                of >= 2^24 global node rows: returns on unsorted rows like the sorted one) */
   double avg_degree;                         /* edges per source row the pass-C choice was made on                  */
 } mtmc_mpn_plan;
 int32_t mtmc_mpn_plan_call(const mtmc_mpn_model* model, const mtmc_mpn_call* call, mtmc_mpn_plan* out);

@@ -68,6 +68,20 @@ def test_single_gpu_regimes(eng):
     assert trn.pass_c == _lib.PASS_C_WALK and not trn.lazy_edges     # Dropout in the node update; e' kept for the tape
 
 
+def test_deterministic_mode_beyond_the_sorted_kernels_node_limit(eng):
+    """Round-3 regression (ADVICE): with >= 2^24 GLOBAL node rows (reachable with row-sharded multi-GPU calls) a many-edge
+    call runs the any-order matrix-core kernel, which only knows float atomics; a deterministic call must keep the walk
+    there (its carry[] is what agg_fixup_kernel adds up), and the plan must name the kernel that really runs."""
+    big_n = 1 << 24
+    rows, e_loc, e_tot = (0, 1 << 21), 300_000_000, 2_000_000_000
+    det = eng.plan(big_n, e_loc, e_tot, node_range=rows, row_range=rows, flags=_lib.F_DETERMINISTIC)
+    assert det.avg_degree > 24 and det.pass_c == _lib.PASS_C_WALK
+    plain = eng.plan(big_n, e_loc, e_tot, node_range=rows, row_range=rows)
+    assert plain.pass_c == _lib.PASS_C_MFMA_ANY         # not MFMA_SORTED: launch_pass_c cannot take the sorted kernel here
+    below = eng.plan(big_n - 1, e_loc, e_tot, node_range=rows, row_range=rows, flags=_lib.F_DETERMINISTIC)
+    assert below.pass_c == _lib.PASS_C_MFMA_SORTED
+
+
 def test_plan_rejects_inconsistent_ranges(eng):
     with pytest.raises(RuntimeError):
         eng.plan(100, 50, 10)                           # more local edges than the graph has
