@@ -4,9 +4,14 @@ the ranks of one node, one process per GPU, RCCL (torch.distributed backend "ncc
 Launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
-Strong scaling: the graph is fixed, each rank streams E/N edges and encodes N_nodes/N node rows; the replicated
-[N,32] node state is all-reduced after every round (mtmc_mpn/distributed.py).  value = total edges / step time,
-step time = max over ranks between two barriers.
+Strong scaling: the graph is fixed and row-sorted, so every rank gets a row-complete edge shard (boundaries snapped to
+row changes), encodes and projects exactly the node rows its edges start from, and keeps their node state to itself: per
+round only the column projections Pc [N,4] are all-gathered (16 B per node instead of the 128 B of the node state), the
+BatchNorm statistics are all-reduced at their dependency points (14 collectives per L = 3 forward, mtmc_mpn/distributed.py
+step_plan), and the [N,32] node state is all-gathered once at the end.  value = total edges / step time, step time = max
+over ranks between two barriers.  The line also carries `prediction`: the per-rank kernel time by phase scaled from the
+committed 1-GPU profile and the expected time of every collective over xGMI, next to what was
+measured.
 """
 import copy
 import json
@@ -20,6 +25,67 @@ import mtmc_mpn
 from mtmc_mpn import _lib, distributed as mdist, graphs
 
 ARCH = "resnet101"
+
+
+# ---- what the first real multi-GPU run is held against -------------------------------------------
+XGMI_LINK_GBS = 153.0          # one xGMI link, one direction (7 per GPU, one to every peer); the run is priced at
+XGMI_EFF = 0.65                # 65 % of it for large messages -- a ring step moves one piece over one link
+SMALL_COLLECTIVE_US = 20.0     # an RCCL all-reduce of a few KB (latency-bound; 15-25 us typical on one node)
+LAUNCH_FLOOR_US = 5.0          # a dependent kernel at its floor (the S02 forward: 25 launches at 4-13 us)
+
+
+def predict_scaling(world, n=1_000_000, e=100_000_000, L=3, stats_csv=None):
+    """Expected per-rank time of one config-5 forward on `world` ranks (row-complete shards, own rows): kernel time by phase
+    = the committed 1-GPU rocprofv3 averages (profiles/rNN_cfg5_kernel_stats.csv) / world -- every kernel of the path works on
+    the rank's own edges or own rows; what does NOT shrink is named -- plus every collective priced over xGMI."""
+    import csv
+    import glob
+    if stats_csv is None:
+        found = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_cfg5_kernel_stats.csv")))
+        if not found:
+            return None
+        stats_csv = found[-1]
+    avg, calls = {}, {}
+    for r in csv.DictReader(open(stats_csv)):
+        if r.get("AverageNs"):
+            avg[r["Name"]] = float(r["AverageNs"]) * 1e-6          # ms per launch
+            calls[r["Name"]] = int(r["Calls"])
+    steps = min(calls.values()) if calls else 1
+
+    def per_forward(prefix):                                          # all launches of the kernels named prefix*, per forward
+        return sum(avg[k] * calls[k] / steps for k in avg if k.startswith(prefix))
+    phases = {
+        "encoder layer 0 (operand split + gemm_f16p_m16)": per_forward("mtmc::gemm_f16p") + per_forward("mtmc::split_rows"),
+        "encoder layers 1-3 (gemm_staged, gemm_rows)": per_forward("mtmc::gemm_staged") + per_forward("mtmc::gemm_rows"),
+        "prep + enc2 (edge branch)": per_forward("mtmc::prep") + per_forward("mtmc::enc2"),
+        "pass_a x L (gathers Pc of ALL nodes: per-edge cost does not improve with P)": per_forward("mtmc::pass_a"),
+        "pass_b x L": per_forward("mtmc::pass_b"),
+        "pass_c x L": per_forward("mtmc::pass_c_sorted") + per_forward("mtmc::pass_c_kernel"),
+        "node_proj + node_stat x L (own rows)": per_forward("mtmc::node_proj") + per_forward("mtmc::node_stat"),
+    }
+    one_gpu = sum(phases.values())
+    n_launch = 14 + 5 * L + 1
+    kernels = {k: v / world for k, v in phases.items()}
+    kernel_ms = sum(kernels.values()) + (n_launch * LAUNCH_FLOOR_US * 1e-3 if world > 1 else 0.0) * (1 - 1 / world)
+    bw = XGMI_LINK_GBS * XGMI_EFF * 1e9
+    ring = lambda total_bytes: (world - 1) * (total_bytes / world) / bw * 1e3 + SMALL_COLLECTIVE_US * 1e-3   # ms
+    coll = []
+    if world > 1:
+        coll.append({"what": "BatchNorm statistics all-reduce (fp64, 0.5-18 KB)", "count": 4 + 2 * L,
+                     "bytes_each": "<= 18 KB", "ms_each": SMALL_COLLECTIVE_US * 1e-3})
+        coll.append({"what": "all-gather of the column projections Pc [N,4] f32", "count": L, "bytes_each": 16 * n,
+                     "ms_each": ring(16 * n)})
+        coll.append({"what": "final all-gather of the node state [N,32] f32 (replicate_h=False drops it)", "count": 1,
+                     "bytes_each": 128 * n, "ms_each": ring(128 * n)})
+    coll_ms = sum(c["count"] * c["ms_each"] for c in coll)
+    total = kernel_ms + coll_ms
+    return {"world": world, "source": os.path.basename(stats_csv), "one_gpu_kernel_ms": round(one_gpu, 3),
+            "per_rank_kernel_ms_by_phase": {k: round(v, 3) for k, v in kernels.items()},
+            "per_rank_kernel_ms": round(kernel_ms, 3), "collectives": coll, "collectives_ms": round(coll_ms, 3),
+            "n_collectives": sum(c["count"] for c in coll), "predicted_ms_per_step": round(total, 3),
+            "predicted_edges_per_s": e / (total * 1e-3), "predicted_speedup_vs_1gpu": round(one_gpu / total, 2),
+            "assumptions": f"xGMI link {XGMI_LINK_GBS} GB/s x {XGMI_EFF} efficiency, ring all-gather ((P-1)/P of the bytes over one "
+                           f"link), {SMALL_COLLECTIVE_US} us per small all-reduce, nothing overlapped"}
 
 
 def main_distributed(args):
@@ -126,6 +192,11 @@ def main_distributed(args):
         def host_add(key, t0):
             host_ms[key] = host_ms.get(key, 0.0) + (time.perf_counter() - t0) * 1e3
 
+        SHORT = {_lib.PH_BEGIN: "begin", _lib.PH_EDGE_ENC: "edge_enc", _lib.PH_NODE_ENC: "enc", _lib.PH_NODE_COMBINE: "comb",
+                 _lib.PH_NODE_H0: "h0", _lib.PH_ROUND_PROJ: "proj", _lib.PH_ROUND_A: "A", _lib.PH_ROUND_B: "B",
+                 _lib.PH_ROUND_STAT: "stat", _lib.PH_ROUND_C: "C", _lib.PH_END: "end"}
+        WITH_ARG = (_lib.PH_NODE_ENC, _lib.PH_NODE_COMBINE)
+
         class TimedBackend:
             """The engine's phase interface with a host clock around run_phase (everything else passes through)."""
             def __init__(self, inner):
@@ -134,10 +205,10 @@ def main_distributed(args):
             def __getattr__(self, name):
                 return getattr(self._inner, name)
 
-            def run_phase(self, prep, ph, arg):
+            def run_phase_list(self, prep, pairs):
                 t0 = time.perf_counter()
-                self._inner.run_phase(prep, ph, arg)
-                host_add(bench.PHASE_NAMES.get(ph, str(ph)), t0)
+                self._inner.run_phase_list(prep, pairs)        # one library call: everything between two collectives
+                host_add("+".join(SHORT.get(ph, str(ph)) + (str(arg) if ph in WITH_ARG else "") for ph, arg in pairs), t0)
 
         class Timed(mdist.ShardedForward):
             def _timed(self, fn, *a_):
@@ -204,7 +275,7 @@ def main_distributed(args):
         dist.all_reduce(t2, op=dist.ReduceOp.MAX)
         s02 = {"workload": "s02 (N=450, E=150454, L=3) edge-partitioned over the same ranks", "ms_per_step": float(t2) * 1e3,
                "edges_per_s": e2 / float(t2),
-               "note": "latency-bound graph: ~30 small collectives per forward outweigh the 0.17 ms of kernels"}
+               "note": "latency-bound graph: the 14 small collectives per forward outweigh the 0.17 ms of kernels"}
 
     if rank == 0:
         b_fwd = bench.algorithmic_bytes_forward(n, e, L, cs)
@@ -226,6 +297,7 @@ def main_distributed(args):
                 "forward_algorithmic": {"bytes": b_fwd, "GBps": b_fwd / sec / 1e9,
                                         "frac_of_aggregate_hbm_peak": b_fwd / sec / 1e9 / (bench.HBM_PEAK_GBS * world)},
                 "rank0_split": split, "per_rank_host": per_rank, "parity_vs_1gpu": parity,
+                "prediction": predict_scaling(world, n, e, L) if name == "cfg5" else None,
                 "ms_per_step_with_sharded_node_state": None if sec_sharded_h is None else sec_sharded_h * 1e3}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())

@@ -54,7 +54,7 @@ class Call(C.Structure):
 
 class WsLayout(C.Structure):
     _fields_ = [("total_bytes", C.c_size_t), ("zero_bytes", C.c_size_t), ("flags_off", C.c_size_t),
-                ("stat_attr_off", C.c_size_t), ("stat_enc2_off", C.c_size_t), ("stat_enc_node_off", C.c_size_t),
+                ("stat_attr_off", C.c_size_t), ("stat_enc2_off", C.c_size_t), ("stat_enc_layer_off", C.c_size_t * MAX_ENC_LAYERS),
                 ("stat_round_off", C.c_size_t), ("deg_off", C.c_size_t), ("seg_off", C.c_size_t),
                 ("h0_off", C.c_size_t), ("h_acc_off", C.c_size_t * 2), ("deg_global_off", C.c_size_t),
                 ("P_off", C.c_size_t)]
@@ -73,11 +73,11 @@ PASS_C_WALK, PASS_C_MFMA_SORTED, PASS_C_MFMA_ANY = range(3)
 # statistics blocks (include/mtmc_mpn.h): replicas x stride doubles each
 STAT_REPLICAS, ATTR_STRIDE, ENC2_STRIDE, Z1_STRIDE, M_STRIDE, Z2_STRIDE = 16, 16, 16, 16, 16, 64
 ROUND_BLOCK = STAT_REPLICAS * (Z1_STRIDE + M_STRIDE + Z2_STRIDE)
-F_DETERMINISTIC, F_GLOBAL_DEG, F_FORK = 1, 4, 2
+F_DETERMINISTIC, F_GLOBAL_DEG, F_FORK, F_WEIGHTS_CACHED = 1, 4, 2, 8
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmtmc_mpn.so")
 EXPORTS = ["mtmc_mpn_abi_version", "mtmc_mpn_last_error", "mtmc_mpn_workspace_bytes", "mtmc_mpn_workspace_layout",
-           "mtmc_mpn_forward", "mtmc_mpn_run_phase", "mtmc_mpn_plan_call", "mtmc_scatter_add", "mtmc_scatter_add_i64", "mtmc_scatter_mean", "mtmc_scatter_max",
+           "mtmc_mpn_forward", "mtmc_mpn_run_phase", "mtmc_mpn_run_phases", "mtmc_mpn_plan_call", "mtmc_scatter_add", "mtmc_scatter_add_i64", "mtmc_scatter_mean", "mtmc_scatter_max",
            "mtmc_mlp_layer_forward", "mtmc_mpn_train_workspace_bytes", "mtmc_mpn_backward", "mtmc_graph_workspace_bytes",
            "mtmc_build_graph", "mtmc_postprocess_workspace_bytes", "mtmc_postprocess",
            "mtmc_cross_entropy_forward", "mtmc_cross_entropy_backward",
@@ -157,6 +157,8 @@ def load() -> C.CDLL:
     lib.mtmc_mpn_plan_call.argtypes = [C.POINTER(Model), C.POINTER(Call), C.POINTER(Plan)]
     lib.mtmc_mpn_run_phase.restype = C.c_int32
     lib.mtmc_mpn_run_phase.argtypes = [C.POINTER(Model), C.POINTER(Call), C.c_int32, C.c_int32]
+    lib.mtmc_mpn_run_phases.restype = C.c_int32
+    lib.mtmc_mpn_run_phases.argtypes = [C.POINTER(Model), C.POINTER(Call), C.POINTER(C.c_int32), C.c_int32]
     for name in ("mtmc_scatter_add", "mtmc_scatter_add_i64"):
         getattr(lib, name).restype = C.c_int32
         getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
@@ -173,26 +175,6 @@ def load() -> C.CDLL:
         raise RuntimeError("mtmc_mpn: ABI version mismatch between _lib.py and libmtmc_mpn.so")
     _lib = lib
     return lib
-
-
-LAB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmtmc_lab.so")
-_lab = None
-
-
-def load_lab() -> C.CDLL:
-    """The kernel laboratory (csrc/lab/, libmtmc_lab.so): A/B variants and timing experiments of the pre-split GEMM for
-    tools/presplit_time.py and tests/test_gpu_gemm_presplit.py.  Test / tool infrastructure -- the package never loads it."""
-    global _lab
-    if _lab is None:
-        load()
-        if not os.path.exists(LAB_PATH):
-            raise RuntimeError(f"mtmc_mpn: {LAB_PATH} missing; run `python -m mtmc_mpn.build`")
-        _lab = C.CDLL(LAB_PATH)
-        _lab.mtmc_lab_linear_presplit_raw.restype = C.c_int32
-        _lab.mtmc_lab_linear_presplit_raw.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
-                                                      C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
-                                                      C.c_int32, C.c_void_p]
-    return _lab
 
 
 def check(rc: int):

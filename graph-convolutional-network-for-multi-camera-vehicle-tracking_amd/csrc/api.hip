@@ -65,6 +65,15 @@ int32_t mtmc_mpn_run_phase(const mtmc_mpn_model* model, const mtmc_mpn_call* cal
   return run_phase(x, phase, arg);
 }
 
+int32_t mtmc_mpn_run_phases(const mtmc_mpn_model* model, const mtmc_mpn_call* call, const int32_t* phase_args, int32_t n) {
+  Ctx x;
+  if (int rc = make_ctx(model, call, &x)) return rc;
+  if (n < 0 || (n > 0 && !phase_args)) return fail(MTMC_E_ARG, "mtmc_mpn_run_phases: bad phase list");
+  for (int i = 0; i < n; ++i)
+    if (int rc = run_phase(x, phase_args[2 * i], phase_args[2 * i + 1])) return rc;
+  return MTMC_OK;
+}
+
 int32_t mtmc_mpn_plan_call(const mtmc_mpn_model* model, const mtmc_mpn_call* call, mtmc_mpn_plan* out) {
   if (int rc = check_model(model)) return rc;
   if (!out) return fail(MTMC_E_ARG, "mtmc_mpn_plan_call: NULL result");

@@ -30,7 +30,9 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 struct Layout {
   mtmc_ws_layout pub;
   size_t row32, col32, e_buf[2], P, Q, slab, enc_aff, row_start, carry;
-  size_t amax;                                 // u32[1 + 2*MTMC_MAX_ENC_LAYERS]: |x|max, |W_l|max, |Y_l|max (zeroed)
+  size_t amax;                                 // u32[1 + 2*MTMC_MAX_ENC_LAYERS][kAmaxRep]: |x|max, -, |Y_l|max (zeroed)
+  size_t amax_w;                               // u32[MTMC_MAX_ENC_LAYERS][kAmaxRep]: |W_l|max of the in-loop layers -- the LAST
+                                               // block of the zeroed head: a call with MTMC_F_WEIGHTS_CACHED leaves it alone
   size_t Y[MTMC_MAX_ENC_LAYERS];
   size_t stat_enc_layer[MTMC_MAX_ENC_LAYERS];
   // training: every round keeps its own buffers (the workspace is the backward tape) + backward scratch
@@ -85,20 +87,18 @@ inline void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* l
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
   const int L = m->num_enc_steps;
   lo->pub.flags_off = take(8 * sizeof(int32_t));
+  // the edge branch's two statistics blocks sit right in front of node-encoder layer 0's / layer 1's column statistics: a
+  // multi-GPU host all-reduces each pair as ONE message (mtmc_ws_layout, distributed.py)
   lo->pub.stat_attr_off = take((size_t)mtmc::kStatRep * mtmc::kAttrStride * sizeof(double));
+  lo->stat_enc_layer[0] = take(2 * (size_t)m->enc_node[0].out_dim * sizeof(double));
   lo->pub.stat_enc2_off = take((size_t)mtmc::kStatRep * mtmc::kEnc2Stride * sizeof(double));
-  size_t enc_stats = 0;
-  for (int l = 0; l < m->n_enc_layers; ++l) enc_stats += 2 * (size_t)m->enc_node[l].out_dim;
-  lo->pub.stat_enc_node_off = take(enc_stats * sizeof(double));
-  size_t acc = 0;
-  for (int l = 0; l < m->n_enc_layers; ++l) {
-    lo->stat_enc_layer[l] = lo->pub.stat_enc_node_off + acc * sizeof(double);
-    acc += 2 * (size_t)m->enc_node[l].out_dim;
-  }
+  for (int l = 1; l < m->n_enc_layers; ++l) lo->stat_enc_layer[l] = take(2 * (size_t)m->enc_node[l].out_dim * sizeof(double));
+  for (int l = 0; l < m->n_enc_layers; ++l) lo->pub.stat_enc_layer_off[l] = lo->stat_enc_layer[l];
   lo->pub.stat_round_off = take((size_t)(L > 0 ? L : 1) * mtmc::kRoundBlock * sizeof(double));
   lo->pub.deg_off = take((size_t)N * sizeof(int32_t));
   lo->pub.seg_off = take((size_t)N * 4 * sizeof(double));
   lo->amax = take((size_t)(1 + 2 * MTMC_MAX_ENC_LAYERS) * mtmc::kAmaxRep * sizeof(uint32_t));
+  lo->amax_w = take((size_t)MTMC_MAX_ENC_LAYERS * mtmc::kAmaxRep * sizeof(uint32_t));
   lo->pub.zero_bytes = off;
   lo->pub.deg_global_off = take((size_t)N * sizeof(int32_t));
   lo->pub.h0_off = take((size_t)N * 32 * sizeof(float));
@@ -350,7 +350,11 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
     case MTMC_PH_BEGIN:
     case kPhMemset:
     case kPhPrep: {
-      if (phase != kPhPrep && hipMemsetAsync(x.ws, 0, x.lo.pub.zero_bytes, s) != hipSuccess)
+      // MTMC_F_WEIGHTS_CACHED (eval mode): everything derived from the WEIGHTS alone -- the fp16 planes + row scales of W0 and
+      // of the staged layers, the |W_l|max words of the in-loop layers -- is still in this workspace from the previous call
+      // (same weights, same sizes: the host's promise); it is neither cleared nor derived again
+      const bool w_cached = (c->flags & MTMC_F_WEIGHTS_CACHED) && !c->training;
+      if (phase != kPhPrep && hipMemsetAsync(x.ws, 0, w_cached ? x.lo.amax_w : x.lo.pub.zero_bytes, s) != hipSuccess)
         return fail(MTMC_E_HIP, "hipMemsetAsync failed");
       if (phase != kPhMemset) {
         mtmc::PrepParams p;
@@ -365,19 +369,20 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
         const bool pre0 = use_presplit0(x);
         if (c->node_hi > c->node_lo) {
           if (!pre0) p.jobs[p.n_jobs++] = {c->x, c->node_hi - c->node_lo, m->enc_node[0].in_dim, c->x_row_stride, amax, 0, 0};
-          for (int l = pre0 ? 1 : 0; l < m->n_enc_layers; ++l)
+          for (int l = pre0 ? 1 : 0; l < m->n_enc_layers && !w_cached; ++l)
             if (!use_staged(x, l) && !use_rows(x, l))   // (staged: weights split into planes below; row-streaming: in the kernel)
               p.jobs[p.n_jobs++] = {m->enc_node[l].weight, m->enc_node[l].out_dim, m->enc_node[l].in_dim,
-                                    m->enc_node[l].in_dim, amax + (1 + l) * mtmc::kAmaxRep, 0, 0};
+                                    m->enc_node[l].in_dim, x.at<unsigned>(x.lo.amax_w) + l * mtmc::kAmaxRep, 0, 0};
         }
         mtmc::launch_prep(p, s);
         if (pre0) {     // instead of the |.|max of x and W0: their fp16 planes and row scales (one pass over each)
           mtmc::launch_split_rows(c->x, c->x_row_stride, c->node_hi - c->node_lo, m->enc_node[0].in_dim, x.at<void>(x.lo.xh),
                                   x.at<float>(x.lo.inv_a), s);
-          mtmc::launch_split_rows(m->enc_node[0].weight, m->enc_node[0].in_dim, m->enc_node[0].out_dim,
-                                  m->enc_node[0].in_dim, x.at<void>(x.lo.wh), x.at<float>(x.lo.inv_w), s);
+          if (!w_cached)
+            mtmc::launch_split_rows(m->enc_node[0].weight, m->enc_node[0].in_dim, m->enc_node[0].out_dim,
+                                    m->enc_node[0].in_dim, x.at<void>(x.lo.wh), x.at<float>(x.lo.inv_w), s);
         }
-        if (c->node_hi > c->node_lo)
+        if (c->node_hi > c->node_lo && !w_cached)
           for (int l = 1; l < m->n_enc_layers; ++l)
             if (use_staged(x, l))
               mtmc::launch_split_rows(m->enc_node[l].weight, m->enc_node[l].in_dim, m->enc_node[l].out_dim,
@@ -440,7 +445,7 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
       {
         unsigned* amax = x.at<unsigned>(x.lo.amax);
         g.amax_a = arg == 0 ? amax : amax + (1 + MTMC_MAX_ENC_LAYERS + (arg - 1)) * mtmc::kAmaxRep;
-        g.amax_w = amax + (1 + arg) * mtmc::kAmaxRep;
+        g.amax_w = x.at<unsigned>(x.lo.amax_w) + arg * mtmc::kAmaxRep;
         g.amax_y = amax + (1 + MTMC_MAX_ENC_LAYERS + arg) * mtmc::kAmaxRep;
       }
       if (use_rows(x, arg)) {

@@ -194,7 +194,7 @@ static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
       if (l > 0 || d_x) {
         mtmc::launch_transpose_pad(Lr.weight, d, in, in, tW, d, s);   // tW [in][d]
         g.A = gA; g.lda = d; g.W = tW; g.Y = l > 0 ? gB : d_x; g.ldy = in; g.M = N; g.K = d; g.Nout = in;
-        g.amax_w = amax_fwd + (size_t)(1 + l) * mtmc::kAmaxRep;
+        g.amax_w = x.at<unsigned>(lo.amax_w) + (size_t)l * mtmc::kAmaxRep;
         if (mtmc::launch_gemm_bn(g, s) != MTMC_OK) return fail(MTMC_E_ARG, "backward: input-gradient GEMM shape");
         std::swap(gA, gB);
       }

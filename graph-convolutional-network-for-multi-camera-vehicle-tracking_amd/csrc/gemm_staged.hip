@@ -26,9 +26,6 @@
 
 namespace mtmc {
 
-#ifndef SG_ABL
-#define SG_ABL 0          // timing ablations (tools/staged_ablate.sh); results are garbage for any value but 0
-#endif
 #ifndef SG_STAMP
 #define SG_STAMP 0        // 1: workgroup 0 records s_memtime at four points of every k-tile, per wave (tools/staged_stamps.py)
 #endif
@@ -146,23 +143,16 @@ __global__ __launch_bounds__(kSgNT) void gemm_staged_kernel(StagedGemmParams p, 
     auto load_a = [&](int kt, int set) {
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
-        if (SG_ABL == 2 || SG_ABL == 6) ra[set][h] = float4{(float)kt, 1.f, 2.f, (float)h};
-        else ra[set][h] = *reinterpret_cast<const float4*>(a_src[h] + kt * kSgBK);
+        ra[set][h] = *reinterpret_cast<const float4*>(a_src[h] + kt * kSgBK);
       }
     };
     auto convert_a = [&](int kt, int set) {
-      if (SG_ABL == 6) return;
       unsigned char* st = smem + A0 + (kt & 1) * AST;
       const float4 s4 = *reinterpret_cast<const float4*>(s_in + kt * kSgBK + c8 * 4);
       const float4 t4 = *reinterpret_cast<const float4*>(t_in + kt * kSgBK + c8 * 4);
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         const float4 v = ra[set][h];
-        if (SG_ABL == 1) {                                  // no conversion arithmetic: the loaded bits go straight to LDS
-          *reinterpret_cast<uint2*>(st + a_dst[h]) = uint2{__float_as_uint(v.x), __float_as_uint(v.y)};
-          *reinterpret_cast<uint2*>(st + AIMG + a_dst[h]) = uint2{__float_as_uint(v.z), __float_as_uint(v.w)};
-          continue;
-        }
         // relu(bn(y)) scaled into fp16's range, then h1 = rtz(x), h2 = rtz(x - h1) (exact residual; see gemm_bn.hip `put`).
         // (Folding the scale into s4 / t4 and one LDS address per row -- six instructions per float4 less -- measured
         // 3 % SLOWER, 368 against 358 us on layer 1 of config 4, same box: kept as it was.)
@@ -223,7 +213,6 @@ __global__ __launch_bounds__(kSgNT) void gemm_staged_kernel(StagedGemmParams p, 
     const int64_t w_plane = (int64_t)p.Nout * p.K * 2, w_kt = (int64_t)p.Nout * kSgBK * 2;
     // one of the wave's 2 * WJ LDS-DMA instructions of k-tile kt (g = piece * WJ + pass)
     auto dma_one = [&](int kt, int g) {
-      if (SG_ABL == 4) return;
       const int q = g / WJ, j = g % WJ;
       lds_dma16(w_tile + q * w_plane + kt * w_kt, off_w[j], lds0 + (kt % kSgNW) * WST + cw * 1024 + q * WIMG + j * 8192);
     };
@@ -255,8 +244,7 @@ __global__ __launch_bounds__(kSgNT) void gemm_staged_kernel(StagedGemmParams p, 
       for (int j = 0; j < TJ; ++j)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          if (SG_ABL == 5) b[j][q] = f16x8{(_Float16)kt, 1, 2, 3, 4, 5, 6, (_Float16)j};
-          else b[j][q] = *reinterpret_cast<const f16x8*>(st + q * WIMG + b_row + j * 16 * kSgRowB);
+          b[j][q] = *reinterpret_cast<const f16x8*>(st + q * WIMG + b_row + j * 16 * kSgRowB);
         }
       // the A fragments of block i + 1 are read BEFORE block i's MFMAs (two register sets): read right before their use,
       // every block began with an exposed LDS round trip
@@ -264,8 +252,7 @@ __global__ __launch_bounds__(kSgNT) void gemm_staged_kernel(StagedGemmParams p, 
       auto read_a = [&](int i, int set) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          if (SG_ABL == 5) af[set][q] = f16x8{(_Float16)kt, 1, 2, 3, 4, 5, 6, (_Float16)i};
-          else af[set][q] = *reinterpret_cast<const f16x8*>(as + q * AIMG + a_row + i * 16 * kSgRowB);
+          af[set][q] = *reinterpret_cast<const f16x8*>(as + q * AIMG + a_row + i * 16 * kSgRowB);
         }
       };
       read_a(0, 0);
@@ -276,10 +263,6 @@ __global__ __launch_bounds__(kSgNT) void gemm_staged_kernel(StagedGemmParams p, 
         if (i < nblk) {                                    // (rows past the tile's height: wave-uniform skip)
 #pragma unroll
           for (int j = 0; j < TJ; ++j) {                   // the three products of a block back to back (gemm_presplit.hip)
-            if (SG_ABL == 3) {                             // no matrix work: the fragments are only kept alive
-              asm volatile("" ::"v"(a[0]), "v"(a[1]), "v"(b[j][0]), "v"(b[j][1]));
-              continue;
-            }
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], b[j][0], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[j][0], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[j][1], acc[i][j], 0, 0, 0);

@@ -7,9 +7,10 @@ features stay local for the encoder GEMMs).  The 32-wide node state is replicate
 
 Exchanges per forward -- BatchNorm couples every row, so each statistics block is all-reduced (fp64, a few
 hundred bytes to a few KB each), plus the two real data exchanges:
-    after BEGIN      edge_attr moments                     (+ the degree, for mean aggregation only)
-    after EDGE_ENC   hidden edge-encoder moments
-    after NODE_COMBINE l  column statistics of encoder layer l
+    after BEGIN + NODE_ENC/COMBINE 0      edge_attr moments + column statistics of encoder layer 0: ONE message
+                                          (+ the degree, for mean aggregation only)
+    after EDGE_ENC + NODE_ENC/COMBINE 1   hidden edge-encoder moments + column statistics of layer 1: ONE message
+    after NODE_COMBINE l >= 2             column statistics of encoder layer l
     after NODE_H0    all-gather of the encoded node rows h0                       [N,32] f32
     per round        z1 statistics, then e' moments + z2 statistics together (two small all-reduces)
                      all-reduce (sum or max) of the aggregated node state h'      [N,32] f32
@@ -20,10 +21,11 @@ hundred bytes to a few KB each), plus the two real data exchanges:
 The per-node segment sums and degrees need no exchange: the z2 statistics are linear in them, so every rank
 evaluates its share and only the 64 sums travel.
 
-The phase sequence itself is the single-GPU one (ForwardEngine.phase_list / mtmc_mpn_run_phase); this file only
-decides what is exchanged after which phase.  It talks to the kernels through the small backend interface
-(prepare / phase_list / run_phase / region / outputs), which is what lets tests/ drive the same code with a CPU
-stand-in over gloo.
+The phases are the single-GPU ones (mtmc_mpn_run_phases); this file decides their order (`step_plan`: the node
+encoder's first layers run beside the edge branch so that their statistics share a message), what is exchanged behind
+which of them, and issues everything between two collectives as ONE library call.  It talks to the kernels through the
+small backend interface (prepare / run_phase_list / region / outputs / set_flags), which is what lets tests/ drive the
+same code with a CPU stand-in over gloo.
 """
 from __future__ import annotations
 
@@ -76,6 +78,45 @@ def tile_rows(row_ranges, n_nodes):
     if not order:
         tiled[0] = (0, n_nodes)
     return tiled
+
+
+def step_plan(spec, local_rows: bool, own_rows: bool):
+    """One forward as [(phases, (exchange, index))]: `phases` = the (phase, arg) pairs that run back to back in one
+    library call, `exchange` = what travels behind them (None: nothing).  The statistics all-reduces sit at the dependency
+    points only, and the edge branch's two ride with the node encoder's first two (their blocks are adjacent in the
+    workspace): L = 3 on row-complete shards = 4 + 3 * 3 collectives + the final node state, 14 in all -- against one
+    library call and one collective per phase before (about 30).  Dependencies: EDGE_ENC needs the reduced edge_attr moments
+    (BEGIN), encoder layer l + 1 the reduced column statistics of layer l, round 0 the reduced hidden edge-encoder moments;
+    inside a round pass A needs all of Pc, pass B the z1 statistics, pass C the e'-moment + z2 statistics; on row-complete
+    shards pass C of round r and the projection of round r + 1 need nothing from other ranks in between."""
+    P = _lib
+    n_layers, L = len(spec.enc_node), spec.num_enc_steps
+    steps = [([(P.PH_BEGIN, 0), (P.PH_NODE_ENC, 0), (P.PH_NODE_COMBINE, 0)], ("enc_merged", 0))]
+    if n_layers > 1:
+        steps.append(([(P.PH_EDGE_ENC, 0), (P.PH_NODE_ENC, 1), (P.PH_NODE_COMBINE, 1)], ("enc_merged", 1)))
+    else:
+        steps.append(([(P.PH_EDGE_ENC, 0)], ("stat_enc2", 0)))
+    for l in range(2, n_layers):
+        steps.append(([(P.PH_NODE_ENC, l), (P.PH_NODE_COMBINE, l)], ("stat_enc_node", l)))
+    pending = [(P.PH_NODE_H0, 0)]
+    if not own_rows:
+        steps.append((pending, ("h0", 0)))
+        pending = []
+    for r in range(L):
+        pending.append((P.PH_ROUND_PROJ, r))
+        if local_rows:
+            steps.append((pending, ("Pc", r)))
+            pending = []
+        pending.append((P.PH_ROUND_A, r))
+        steps.append((pending, ("round_z1", r)))
+        steps.append(([(P.PH_ROUND_B, r), (P.PH_ROUND_STAT, r)], ("round_m_z2", r)))
+        pending = [(P.PH_ROUND_C, r)]
+        if not local_rows:
+            steps.append((pending, ("agg", r)))
+            pending = []
+    pending.append((P.PH_END, 0))
+    steps.append((pending, (None, 0)))
+    return steps
 
 
 class ShardedForward:
@@ -148,40 +189,35 @@ class ShardedForward:
             raise ValueError(f"rank {rank} must encode node rows {rows[rank]} "
                              f"({'tile_rows(row_ranges, N)' if own_rows else 'even_ranges'}), got {node_range[:2]}")
 
-        for ph, arg in be.phase_list():
-            be.run_phase(prep, ph, arg)
-            if ph == _lib.PH_BEGIN:
-                self._sum(be.region(prep, "stat_attr"))
-                if mean:
+        for phases, (what, idx) in step_plan(spec, local_rows, own_rows):
+            be.run_phase_list(prep, phases)             # ONE library call for everything between two collectives
+            if what == "enc_merged":                    # edge-branch block + encoder layer idx's column statistics: one message
+                for t in be.region(prep, "enc_merged", idx):
+                    self._sum(t)
+                if idx == 0 and mean:                   # (the degree is complete after BEGIN)
                     g = be.region(prep, "deg_global")
                     g.copy_(be.region(prep, "deg"))
-                    if not local_rows:             # row-complete shards: a row's whole degree is already local
+                    if not local_rows:                  # row-complete shards: a row's whole degree is already local
                         self._sum(g)
-            elif ph == _lib.PH_EDGE_ENC:
-                self._sum(be.region(prep, "stat_enc2"))
-            elif ph == _lib.PH_NODE_COMBINE:           # the layer's column statistics are complete here
-                self._sum(be.region(prep, "stat_enc_node", arg))
-            elif ph == _lib.PH_NODE_H0 and not own_rows:
+            elif what in ("stat_enc2", "stat_enc_node", "round_z1"):
+                self._sum(be.region(prep, what, idx))
+            elif what == "round_m_z2":                  # ROUND_STAT reads only local sums (segment sums, degrees, Q), so the
+                for t in be.region(prep, "round_m_z2", idx):   # e' moments of ROUND_B travel with its z2 sums: one message
+                    self._sum(t)
+            elif what == "h0":
                 h0 = be.region(prep, "h0")
                 even = all(hi - lo == rows[0][1] - rows[0][0] for lo, hi in rows)
                 if even and dist.get_backend(self.group) == "nccl":
                     dist.all_gather_into_tensor(h0, h0[rows[rank][0]:rows[rank][1]].clone(), group=self.group)
-                else:                              # uneven split: one broadcast per owner
+                else:                                   # uneven split: one broadcast per owner
                     for r, (lo, hi) in enumerate(rows):
                         if hi > lo:
                             dist.broadcast(h0[lo:hi], src=dist.get_global_rank(self.group, r) if self.group else r,
                                            group=self.group)
-            elif ph == _lib.PH_ROUND_PROJ:
-                if local_rows:                     # every rank gathers along its edges' columns: all of Pc
-                    self._gather_rows(be.region(prep, "Pc"), row_ranges, rank, world)
-            elif ph == _lib.PH_ROUND_A:
-                self._sum(be.region(prep, "round_z1", arg))
-            elif ph == _lib.PH_ROUND_STAT:           # ROUND_STAT reads only local sums (segment sums, degrees, Q), so the
-                for t in be.region(prep, "round_m_z2", arg):   # e' moments of ROUND_B travel with its z2 sums: one message
-                    self._sum(t)
-            elif ph == _lib.PH_ROUND_C:
-                if not local_rows:
-                    (self._max if spec.agg == "max" else self._sum)(be.region(prep, "agg", arg))
+            elif what == "Pc":                          # every rank gathers along its edges' columns: all of Pc
+                self._gather_rows(be.region(prep, "Pc"), row_ranges, rank, world)
+            elif what == "agg":
+                (self._max if spec.agg == "max" else self._sum)(be.region(prep, "agg", idx))
         logits, h = be.outputs(prep)
         if local_rows and replicate_h and (spec.num_enc_steps > 0 or own_rows):   # every rank's rows of the final state
             self._gather_rows(h, row_ranges, rank, world)

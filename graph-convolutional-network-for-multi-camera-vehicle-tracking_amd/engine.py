@@ -22,6 +22,10 @@ def _check_param(p: torch.Tensor, dev) -> int:
     if p.device != dev or p.dtype != torch.float32 or not p.is_contiguous():
         raise RuntimeError("mtmc_mpn: parameters must be contiguous float32 tensors on the input's device "
                            f"(got {p.dtype} on {p.device})")
+    if p.data_ptr() % 16:
+        # the many-row GEMM kernels read weights with 16-byte vector loads and LDS-DMA; a Parameter that is a view at an odd
+        # storage offset would otherwise fail on many-row graphs only (MTMC_E_ARG from the row-streaming kernel)
+        raise RuntimeError("mtmc_mpn: parameters must be 16-byte aligned (a view at an odd storage offset? use .clone())")
     return p.data_ptr()
 
 
@@ -71,6 +75,8 @@ class ForwardEngine:
         self._ws = {}
         self._slots = layer_slots(self.spec)
         self._ms_key, self._ms = None, None
+        self._wkeys = {}                # workspace pointer -> what its weight-derived regions were computed from
+        self.weight_cache = True        # MTMC_F_WEIGHTS_CACHED where valid (torch_ops.NO_WEIGHT_CACHE / module.cache_weight_planes)
         self.flags = 0                  # MTMC_F_* for the calls this engine prepares (torch op argument)
 
     # -- parameters -> mtmc_mpn_model ------------------------------------------------------------
@@ -147,6 +153,25 @@ class ForwardEngine:
             self._ws[key] = ws
         return ws
 
+    def _weights_cached(self, ws, params, sizes) -> bool:
+        """MTMC_F_WEIGHTS_CACHED: True when the LAST call on this workspace derived its weight-only regions (fp16 planes /
+        row scales / |W|max of the node-encoder weights) from the same parameter storage at the same version and for the
+        same sizes -- the library then skips deriving them again.  In-place updates (optimizer.step, copy_, load_state_dict)
+        bump `_version`; a replaced Parameter has another pointer; a graph capture never uses the cache (the weights may
+        change between replays)."""
+        params = self.params() if params is None else params
+        n_enc = len(self.spec.enc_node)
+        key = (sizes,) + tuple((params[4 * l].data_ptr(), params[4 * l]._version) for l in range(n_enc))
+        slot = ws.data_ptr()
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            self._wkeys.pop(slot, None)
+            return False
+        hit = self._wkeys.get(slot) == key
+        if len(self._wkeys) > 64:                       # (workspaces come and go with graph sizes)
+            self._wkeys.clear()
+        self._wkeys[slot] = key
+        return hit
+
     # -- the call -----------------------------------------------------------------------------------
     def check_inputs(self, x, edge_index, edge_attr):
         if not (isinstance(x, torch.Tensor) and x.is_cuda and edge_index.is_cuda and edge_attr.is_cuda):
@@ -222,6 +247,8 @@ class ForwardEngine:
         call.workspace, call.workspace_bytes = ws.data_ptr(), ws.numel()
         call.training, call.seed = (1 if tape else 0), int(seed) & 0xFFFFFFFFFFFFFFFF
         call.flags = int(self.flags) | (_lib.F_DETERMINISTIC if getattr(self.module, "deterministic", False) else 0)
+        if self.weight_cache and not tape and tape_ws is None and self._weights_cached(ws, params, (n, e, node_lo, node_hi)):
+            call.flags |= _lib.F_WEIGHTS_CACHED
         call.stream = stream
         keep = (x, edge_index, edge_attr)        # the structs hold raw pointers: keep the tensors alive
         return types.SimpleNamespace(model=model, call=call, ws=ws, logits=logits, h=h, n_out=n_out, n=n, e=e,
@@ -265,8 +292,14 @@ class ForwardEngine:
         with torch.cuda.device(prep.dev):
             _lib.check(self.lib.mtmc_mpn_run_phase(C.byref(prep.model), C.byref(prep.call), ph, arg))
 
+    def run_phase_list(self, prep, pairs):
+        """Several consecutive phases in one library call (mtmc_mpn_run_phases): what runs between two collectives."""
+        flat = (C.c_int32 * (2 * len(pairs)))(*[v for pair in pairs for v in pair])
+        with torch.cuda.device(prep.dev):
+            _lib.check(self.lib.mtmc_mpn_run_phases(C.byref(prep.model), C.byref(prep.call), flat, len(pairs)))
+
     def set_flags(self, prep, flags):
-        prep.call.flags = int(flags)
+        prep.call.flags = (prep.call.flags & _lib.F_WEIGHTS_CACHED) | int(flags)
 
     def region(self, prep, name, idx=0) -> torch.Tensor:
         """A tensor aliasing one exchanged region of the workspace (include/mtmc_mpn.h, mtmc_ws_layout)."""
@@ -284,8 +317,11 @@ class ForwardEngine:
         if name == "stat_enc2":
             return f64(lay.stat_enc2_off, R * _lib.ENC2_STRIDE)
         if name == "stat_enc_node":
-            off = lay.stat_enc_node_off + 8 * sum(2 * l.out_dim for l in s.enc_node[:idx])
-            return f64(off, 2 * s.enc_node[idx].out_dim)
+            return f64(lay.stat_enc_layer_off[idx], 2 * s.enc_node[idx].out_dim)
+        if name == "enc_merged":               # the edge branch's block + encoder layer idx's (idx 0: stat_attr, 1: stat_enc2),
+            head = lay.stat_attr_off if idx == 0 else lay.stat_enc2_off      # adjacent in the workspace: ONE message
+            end = lay.stat_enc_layer_off[idx] + 16 * s.enc_node[idx].out_dim
+            return (f64(head, (end - head) // 8),)
         if name == "round_m_z2":               # adjacent in the round block: one contiguous message
             base = lay.stat_round_off + 8 * idx * _lib.ROUND_BLOCK + 8 * R * _lib.Z1_STRIDE
             return (f64(base, R * (_lib.M_STRIDE + _lib.Z2_STRIDE)),)

@@ -123,6 +123,10 @@ class MOTMPNet(nn.Module):
         self.num_class_steps = s.num_class_steps
         self.check_indices = False          # True: synchronise and raise IndexError on out-of-range edge_index
         self.deterministic = False          # True: order-independent sum/mean aggregation on row-sorted edge lists
+        # Eval mode: what a forward derives from the node-encoder WEIGHTS alone (fp16 planes / |W|max) is reused by the next
+        # forward of the same size while the parameters' storage and `_version` are unchanged (optimizer steps, copy_ and
+        # load_state_dict bump it).  Writes through `param.data` are invisible to `_version`: set this to False if you do that.
+        self.cache_weight_planes = True
         self._engine = None
 
     # -- the hot path -------------------------------------------------------------------
@@ -182,7 +186,8 @@ class MOTMPNet(nn.Module):
         tape = bool(needs_grad or self.training)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if self.training else 0    # follows torch.manual_seed
         flags = (_lib_flags.F_DETERMINISTIC if self.deterministic else 0) | \
-            (torch_ops.CHECK_INDICES if self.check_indices else 0)
+            (torch_ops.CHECK_INDICES if self.check_indices else 0) | \
+            (0 if self.cache_weight_planes else torch_ops.NO_WEIGHT_CACHE)
         logits, h, _ = torch.ops.mtmc_mpn.mp_forward(x, edge_index, edge_attr, params, self._config_key,
                                                      self.training, seed, flags, tape)
         return {"classified_edges": list(logits.unbind(0))}, h

@@ -30,6 +30,7 @@ from . import _lib
 from . import config as _config
 
 CHECK_INDICES = 1 << 16          # host-side flag bit of `flags`: synchronise and raise IndexError on bad edge_index
+NO_WEIGHT_CACHE = 1 << 17        # host-side: never reuse the weight-derived workspace regions of the previous call
 _ENGINES = {}
 
 
@@ -115,6 +116,7 @@ def _n_out(spec):
 def _mp_forward(x, edge_index, edge_attr, params, config, training, seed, flags, tape):
     eng = engine_for(config)
     eng.flags = int(flags) & 0xFFFF
+    eng.weight_cache = not (int(flags) & NO_WEIGHT_CACHE)
     prep = eng.prepare(x, edge_index, edge_attr, tape=bool(tape), seed=seed, params=list(params))
     if tape and not training:                  # eval-mode statistics / identity Dropout, but still differentiable
         prep.model.dropout_enc = prep.model.dropout_upd_edge = prep.model.dropout_upd_node = 0.0
@@ -187,7 +189,11 @@ def _autograd_backward(ctx, d_logits, d_h, _d_tape):
     if not ctx.has_tape:
         raise RuntimeError("mtmc_mpn: mp_forward was called with tape=False; nothing to differentiate through")
     tape, x, edge_index, edge_attr, *params = ctx.saved_tensors
-    flat, dx, dattr = torch.ops.mtmc_mpn.mp_backward(tape, x, edge_index, edge_attr, params, ctx.config, ctx.training,
+    # mp_backward declares the tape mutable (it clears and fills its backward scratch regions; the forward's saved
+    # activations are only read).  Autograd checks a saved tensor's version on every unpack, so a second backward over the
+    # same graph (retain_graph=True) would refuse the tape after the first one bumped it: hand the op an alias with its own
+    # version counter.  A repeated backward recomputes the same gradients (tests/test_gpu_training.py).
+    flat, dx, dattr = torch.ops.mtmc_mpn.mp_backward(tape.data, x, edge_index, edge_attr, params, ctx.config, ctx.training,
                                                       ctx.seed, ctx.flags, d_logits, d_h, ctx.need_x, ctx.need_attr)
     spec = engine_for(ctx.config).spec
     layout, _ = grad_layout(spec)

@@ -120,6 +120,11 @@ typedef struct mtmc_mpn_call {
 #define MTMC_F_DETERMINISTIC 1   /* row-sorted edge lists: sum/mean aggregation through per-chunk partials added in
                                     a fixed order instead of float atomics (bitwise run-to-run reproducible h) */
 #define MTMC_F_GLOBAL_DEG 4      /* mean aggregation divides by workspace deg_global (multi-GPU) instead of deg */
+#define MTMC_F_WEIGHTS_CACHED 8   /* eval mode: this workspace still holds what the previous call derived from the weights alone
+                                    (fp16 planes and row scales of the pre-split / staged encoder layers, |W|max of the others)
+                                    and the caller promises SAME weight values, SAME n_nodes / n_edges / node range: they are
+                                    not derived again (-3 launches per many-row forward).  Never set it for the first call on a
+                                    workspace, after any other call on it, or while capturing a graph whose weights may change */
 #define MTMC_F_FORK 2            /* run the edge branch (prep, edge-encoder moments) on an internal side stream
                                     beside the node-encoder GEMMs, joined by events (default: one stream) */
 
@@ -137,9 +142,11 @@ typedef struct mtmc_ws_layout {
   size_t total_bytes;
   size_t zero_bytes;         /* the leading region [0, zero_bytes) is cleared by MTMC_PH_BEGIN           */
   size_t flags_off;          /* int32[8]: [0] rows out of order, [1] indices out of range                */
-  size_t stat_attr_off;      /* f64[REPLICAS][ATTR_STRIDE]                                               */
-  size_t stat_enc2_off;      /* f64[REPLICAS][ENC2_STRIDE]                                               */
-  size_t stat_enc_node_off;  /* per encoder layer l, consecutively: f64[2][out_dim_l] column sum | sumsq  */
+  size_t stat_attr_off;      /* f64[REPLICAS][ATTR_STRIDE]; DIRECTLY followed by encoder layer 0's block: a multi-GPU
+                                host all-reduces [stat_attr_off, stat_enc_layer_off[0] + 16 * out_dim_0) as ONE message
+                                after MTMC_PH_NODE_COMBINE 0 (the edge branch's statistics ride with the node encoder's) */
+  size_t stat_enc2_off;      /* f64[REPLICAS][ENC2_STRIDE]; directly followed by encoder layer 1's block (if there is one) */
+  size_t stat_enc_layer_off[MTMC_MAX_ENC_LAYERS];  /* per encoder layer l: f64[2][out_dim_l] column sum | sumsq    */
   size_t stat_round_off;     /* f64[L][ROUND_BLOCK]: per round the z1, e'-moment and z2 blocks in order   */
   size_t deg_off;            /* i32[N]  out-degree of the LOCAL edges (row histogram)                     */
   size_t seg_off;            /* f64[N][4] per-node segment sums of e' over the LOCAL edges                */
@@ -198,6 +205,9 @@ int32_t mtmc_mpn_backward_flat(const mtmc_mpn_model* model, const mtmc_mpn_call*
                                const float* const* d_logits_steps, const float* d_h, float* flat, int64_t flat_floats,
                                float* d_x, float* d_edge_attr);
 int32_t mtmc_mpn_run_phase(const mtmc_mpn_model* model, const mtmc_mpn_call* call, int32_t phase, int32_t arg);
+/* n consecutive (phase, arg) pairs in ONE call (phase_args[2*i], phase_args[2*i+1]): what a multi-GPU host runs between two
+ * of its collectives, without one library call (and one argument check) per phase. */
+int32_t mtmc_mpn_run_phases(const mtmc_mpn_model* model, const mtmc_mpn_call* call, const int32_t* phase_args, int32_t n);
 
 /* Which kernels a call would run -- a host-only query (nothing is launched, no pointer of `call` is read: only its
  * sizes, ranges, flags and `training`), so that a multi-GPU host or a test can check that a SHARD takes the kernels the

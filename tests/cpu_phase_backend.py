@@ -1,7 +1,7 @@
 """CPU stand-in for the HIP phase backend -- TEST INFRASTRUCTURE.
 
 Implements the five-method backend interface of mtmc_mpn.distributed.ShardedForward
-(prepare / phase_list / run_phase / region / outputs) with torch CPU ops, phase by phase, using the same
+(prepare / run_phase_list / region / outputs / set_flags) with torch CPU ops, phase by phase, using the same
 workspace *regions* (names, shapes, replica layout) as csrc/api.hip.  The world_size-2 gloo test drives the
 real orchestration code (which collective on which region after which phase) through it.  The per-phase math
 is tests/phase_model.py's, cut at the same points as the kernels.  Never imported by the product.
@@ -87,11 +87,17 @@ class CpuPhaseBackend:
     def set_flags(self, c, flags):
         c.flags = flags
 
+    def run_phase_list(self, c, pairs):
+        for ph, arg in pairs:
+            self.run_phase(c, ph, arg)
+
     def region(self, c, name, idx=0):
         if name in ("stat_attr", "stat_enc2", "deg", "deg_global", "h0"):
             return getattr(c, name)
         if name in ("stat_enc_node", "round_z1", "round_m", "round_z2"):
             return getattr(c, name)[idx]
+        if name == "enc_merged":                   # (adjacent blocks in the HIP workspace: one message there, two tensors here)
+            return (c.stat_attr if idx == 0 else c.stat_enc2, c.stat_enc_node[idx])
         if name == "round_m_z2":
             return (c.round_m[idx], c.round_z2[idx])
         if name == "Pc":

@@ -73,8 +73,7 @@ def test_single_rank_cpu_backend_matches_golden():
         be = CpuPhaseBackend({k: v.detach() for k, v in m.state_dict().items()}, m.spec)
         with torch.no_grad():
             ctx = be.prepare(d.x, d.edge_index, d.edge_attr)
-            for ph, arg in be.phase_list():
-                be.run_phase(ctx, ph, arg)
+            be.run_phase_list(ctx, be.phase_list())
             logits, h = be.outputs(ctx)
         for i, lg in enumerate(logits):
             assert (lg[c.sub_idx] - c.logits(i)).abs().max().item() <= 1e-4, name
@@ -169,8 +168,7 @@ def test_rows_without_out_edges_in_row_complete_shards(world, own, L, tmp_path):
     be = CpuPhaseBackend({k: v.detach() for k, v in m.state_dict().items()}, m.spec)
     with torch.no_grad():
         ctx = be.prepare(d.x, d.edge_index, d.edge_attr)
-        for ph, arg in be.phase_list():
-            be.run_phase(ctx, ph, arg)
+        be.run_phase_list(ctx, be.phase_list())
         want_logits, want_h = be.outputs(ctx)
     parts = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt")) for r in range(world)]
     for i, w in enumerate(want_logits):
@@ -191,3 +189,47 @@ def test_ranges():
     assert r3[0][0] == 0 and r3[-1][1] == 10 and all(a[1] == b[0] for a, b in zip(r3, r3[1:]))
     for lo, hi in r3[:-1]:
         assert hi == 10 or row[hi] != row[hi - 1]
+
+
+def test_step_plan_collective_count():
+    """<= 14 collectives per L = 3 forward on row-complete shards (was one per phase, ~30), and
+    one library call per collective (everything between two exchanges runs back to back)."""
+    import copy
+    import mtmc_mpn
+    from mtmc_mpn import _lib
+    spec = mtmc_mpn.MOTMPNet(copy.deepcopy(mtmc_mpn.default_params(num_enc_steps=3, num_class_steps=1)), None, "resnet101").spec
+    own = mdist.step_plan(spec, local_rows=True, own_rows=True)
+    exch = [w for _, (w, _) in own if w is not None]
+    assert len(exch) == 13 and len(own) == 14          # + the final all-gather of the node state = 14 collectives
+    assert [w for w in exch[:4]] == ["enc_merged", "enc_merged", "stat_enc_node", "stat_enc_node"]
+    assert exch[4:] == ["Pc", "round_z1", "round_m_z2"] * 3
+    # pass C of round r and the projection of round r + 1 share a library call; END rides with the last pass C
+    assert own[7][0] == [(_lib.PH_ROUND_C, 0), (_lib.PH_ROUND_PROJ, 1)] and own[-1][0] == [(_lib.PH_ROUND_C, 2), (_lib.PH_END, 0)]
+    # every phase of the single-GPU sequence appears exactly once, dependencies in order
+    flat = [pa for phases, _ in own for pa in phases]
+    assert sorted(flat) == sorted([(_lib.PH_BEGIN, 0), (_lib.PH_EDGE_ENC, 0), (_lib.PH_NODE_H0, 0), (_lib.PH_END, 0)] +
+                                  [(p, l) for l in range(4) for p in (_lib.PH_NODE_ENC, _lib.PH_NODE_COMBINE)] +
+                                  [(p, r) for r in range(3) for p in (_lib.PH_ROUND_PROJ, _lib.PH_ROUND_A, _lib.PH_ROUND_B,
+                                                                      _lib.PH_ROUND_STAT, _lib.PH_ROUND_C)])
+    assert flat.index((_lib.PH_BEGIN, 0)) < flat.index((_lib.PH_NODE_ENC, 0)) < flat.index((_lib.PH_EDGE_ENC, 0))
+    gen = mdist.step_plan(spec, local_rows=False, own_rows=False)
+    assert [w for _, (w, _) in gen if w is not None].count("agg") == 3 and ("h0", 0) in [x for _, x in gen]
+
+
+def test_merged_statistics_blocks_are_adjacent_in_the_workspace():
+    """The one-message all-reduces rely on the layout: stat_attr | encoder layer 0, stat_enc2 | encoder layer 1."""
+    import copy
+    import ctypes
+    import mtmc_mpn
+    from mtmc_mpn import _lib, engine
+    m = mtmc_mpn.MOTMPNet(copy.deepcopy(mtmc_mpn.default_params(num_enc_steps=3)), None, "resnet101")
+    eng = engine.ForwardEngine(m)
+    model = eng.model_struct(next(m.parameters()).device)
+    lay = _lib.WsLayout()
+    assert eng.lib.mtmc_mpn_workspace_layout(ctypes.byref(model), 450, 150454, ctypes.byref(lay)) == 0
+    blk = 8 * _lib.STAT_REPLICAS
+    assert lay.stat_attr_off + blk * _lib.ATTR_STRIDE == lay.stat_enc_layer_off[0]
+    assert lay.stat_enc_layer_off[0] + 16 * 1024 == lay.stat_enc2_off
+    assert lay.stat_enc2_off + blk * _lib.ENC2_STRIDE == lay.stat_enc_layer_off[1]
+    assert lay.stat_enc_layer_off[1] + 16 * 512 == lay.stat_enc_layer_off[2] < lay.stat_enc_layer_off[3] < lay.stat_round_off
+    assert lay.stat_round_off < lay.zero_bytes

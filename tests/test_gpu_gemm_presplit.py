@@ -9,6 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(lib, A, W, b, variant, work=None):
+    import lab_lib
     from mtmc_mpn import _lib
     M, K = A.shape
     N = W.shape[0]
@@ -22,7 +23,7 @@ def _run(lib, A, W, b, variant, work=None):
     if variant in ("product", "product-reuse"):
         _lib.check(lib.mtmc_linear_presplit_raw(*args, 1 if variant == "product-reuse" else 0, torch.cuda.current_stream().cuda_stream))
     else:
-        rc = _lib.load_lab().mtmc_lab_linear_presplit_raw(*args, variant, torch.cuda.current_stream().cuda_stream)
+        rc = lab_lib.load_lab().mtmc_lab_linear_presplit_raw(*args, variant, torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             raise RuntimeError(f"mtmc_lab_linear_presplit_raw: code {rc}")
     torch.cuda.synchronize()
@@ -73,6 +74,28 @@ def test_presplit_tile_heights(M):
     assert ymax == Y.abs().max().item()
     assert torch.allclose(st[:N], Y.double().sum(0), rtol=1e-9, atol=1e-9 * Y.abs().max().item() * M)
     assert torch.allclose(st[N:], (Y.double() ** 2).sum(0), rtol=1e-9)
+
+
+@pytest.mark.parametrize("M", [20000, 4100])
+def test_presplit_tile_heights_long_k_tight_bound(M):
+    """The variable-height paths (row blocks skipped per wave, skipped second DMA pass, clamped row offsets of the last
+    tile) at a K where the statistical 3e-7 bound of the other tests applies -- a wrong-row or stale-LDS error in the short
+    tiles cannot hide inside the relaxed short-K budget above.  20000 rows at two column tiles pick 160-row tiles
+    (125 x 2 = 250 tiles: one round), 4100 rows 144-row tiles with a ragged last one."""
+    from mtmc_mpn import _lib
+    lib = _lib.load()
+    K, N = 512, 512
+    g = torch.Generator(device="cuda").manual_seed(M + 1)
+    A = torch.randn(M, K, device="cuda", generator=g) * torch.exp(2 * torch.randn(M, 1, device="cuda", generator=g))
+    W = (torch.rand(N, K, device="cuda", generator=g) * 2 - 1) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    Y, st, ymax, _ = _run(lib, A, W, b, "product")
+    ref = A.double() @ W.double().t() + b.double()
+    bound = A.double().abs() @ W.double().abs().t() + b.double().abs()
+    assert torch.isfinite(Y).all()
+    assert ((Y.double() - ref).abs() / bound).max().item() < 3e-7
+    assert ymax == Y.abs().max().item()
+    assert torch.allclose(st[:N], Y.double().sum(0), rtol=1e-9, atol=1e-9 * Y.abs().max().item() * M)
 
 
 def test_presplit_strided_rows_and_reused_planes():

@@ -15,6 +15,9 @@ import torch  # noqa: E402
 
 from mtmc_mpn import _lib  # noqa: E402
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import lab_lib  # noqa: E402  (the kernel laboratory's loader lives with the tests)
+
 lib = _lib.load()
 M, K, N = 100000, 2048, 1024
 s = torch.cuda.current_stream().cuda_stream
@@ -45,7 +48,7 @@ def run(kind, seconds=4.0):
     st = torch.empty(2 * N, dtype=torch.float64, device="cuda")
 
     def gemm(variant):
-        rc = _lib.load_lab().mtmc_lab_linear_presplit_raw(A.data_ptr(), K, W.data_ptr(), b.data_ptr(), Y.data_ptr(), M, K, N,
+        rc = lab_lib.load_lab().mtmc_lab_linear_presplit_raw(A.data_ptr(), K, W.data_ptr(), b.data_ptr(), Y.data_ptr(), M, K, N,
                                                           work.data_ptr(), work.numel(), scr.data_ptr(), st.data_ptr(), variant, s)
         assert rc == 0, rc
     gemm(9)

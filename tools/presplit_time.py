@@ -10,8 +10,11 @@ import torch  # noqa: E402
 
 from mtmc_mpn import _lib  # noqa: E402
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import lab_lib  # noqa: E402  (the kernel laboratory's loader lives with the tests)
+
 lib = _lib.load()
-lab = _lib.load_lab()            # the A/B variants live in the kernel laboratory (csrc/lab/, libmtmc_lab.so)
+lab = lab_lib.load_lab()            # the A/B variants live in the kernel laboratory (csrc/lab/, libmtmc_lab.so)
 VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "0,9").split(",")]
 s = torch.cuda.current_stream().cuda_stream
 
