@@ -29,6 +29,25 @@ Side* side_for_current_device() {
   return &sd;
 }
 
+// The pipelined layer 0's side stream and events, one set per device.
+SidePipe* pipe_for_current_device() {
+  static SidePipe pipes[64];
+  static bool ok[64];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!ok[dev]) {
+    SidePipe& sp = pipes[dev];
+    if (hipStreamCreateWithFlags(&sp.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&sp.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    for (int i = 0; i < kMaxPanels; ++i)
+      if (hipEventCreateWithFlags(&sp.ready[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    ok[dev] = true;
+  }
+  return &pipes[dev];
+}
+
 }  // namespace
 
 extern "C" {
@@ -101,6 +120,8 @@ int32_t mtmc_mpn_plan_call(const mtmc_mpn_model* model, const mtmc_mpn_call* cal
   out->edges_per_thread = mtmc::plan_edges_per_thread(c->n_edges);
   out->lazy_edges = lazy_edges(c) ? 1 : 0;
   out->avg_degree = avg_degree(c);
+  out->pass_a_col_blocks = (model->num_enc_steps > 0 && mtmc::plan_col_blocks(c->n_nodes, c->n_edges, 1e30, c->training != 0) > 0)
+                               ? mtmc::plan_col_blocks(c->n_nodes, c->n_edges, out->avg_degree, c->training != 0) : 0;
   const bool drop_n = c->training && model->dropout_upd_node > 0.f;
   // the public enum names what launch_pass_c launches: the sorted kernel is MFMA_SORTED, the any-order kernel MFMA_ANY
   // (on a many-edge list it still has the walk launched behind it for unsorted rows)
@@ -113,6 +134,12 @@ int32_t mtmc_mpn_forward(const mtmc_mpn_model* model, const mtmc_mpn_call* call)
   Ctx x;
   if (int rc = make_ctx(model, call, &x)) return rc;
   int rc;
+  // many-row graphs: layer 0 in row panels, the operand split one panel ahead on a side stream (MTMC_L0_PIPELINE=0: off)
+  if (mtmc::knobs().l0_pipeline > 0 && use_presplit0(x)) {
+    int64_t cuts[kMaxPanels + 1];
+    int bm;
+    if (l0_panels(call->node_hi - call->node_lo, model->enc_node[0].out_dim, cuts, &bm) >= 2) x.pipe = pipe_for_current_device();
+  }
   Side* sd = (call->flags & MTMC_F_FORK) ? side_for_current_device() : nullptr;
   if (sd) {
     if ((rc = run_phase(x, MTMC_PH_BEGIN, 0))) return rc;      // prep also gathers the node encoder's operand scales

@@ -30,6 +30,7 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 struct Layout {
   mtmc_ws_layout pub;
   size_t row32, col32, e_buf[2], P, Q, slab, enc_aff, row_start, carry;
+  size_t col_sub; int col_blocks;              // column-blocked pass A: int[N][col_blocks + 1] sub-run boundaries (0 blocks: none)
   size_t amax;                                 // u32[1 + 2*MTMC_MAX_ENC_LAYERS][kAmaxRep]: |x|max, -, |Y_l|max (zeroed)
   size_t amax_w;                               // u32[MTMC_MAX_ENC_LAYERS][kAmaxRep]: |W_l|max of the in-loop layers -- the LAST
                                                // block of the zeroed head: a call with MTMC_F_WEIGHTS_CACHED leaves it alone
@@ -107,6 +108,8 @@ inline void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* l
   lo->enc_aff = take(16 * sizeof(float));
   lo->row_start = take((size_t)N * sizeof(int32_t));
   lo->carry = take((size_t)((E + 31) / 32) * 2 * 32 * sizeof(float));
+  lo->col_blocks = mtmc::plan_col_blocks(N, E, 1e30, training);      // by table size and edge count alone (the call adds the degree)
+  lo->col_sub = take(lo->col_blocks > 0 ? (size_t)N * (lo->col_blocks + 1) * sizeof(int32_t) : 0);
   lo->P = take((size_t)N * 8 * sizeof(float));
   lo->pub.P_off = lo->P;
   lo->Q = take((size_t)N * 32 * sizeof(float));
@@ -182,12 +185,17 @@ inline void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* l
   lo->pub.total_bytes = off;
 }
 
+// Side stream + events of the pipelined layer 0 (api.hip: one set per device, created on first use)
+constexpr int kMaxPanels = 16;
+struct SidePipe { hipStream_t stream; hipEvent_t fork; hipEvent_t ready[kMaxPanels]; };
+
 struct Ctx {
   const mtmc_mpn_model* m;
   const mtmc_mpn_call* c;
   Layout lo;
   char* ws;
   hipStream_t stream;
+  const SidePipe* pipe = nullptr;    // set by mtmc_mpn_forward: layer 0 runs in row panels (split of panel i+1 beside GEMM i)
   template <typename T> T* at(size_t off) const { return reinterpret_cast<T*>(ws + off); }
 };
 
@@ -284,6 +292,12 @@ inline double avg_degree(const mtmc_mpn_call* c) {
 // eval mode, many local edges: e' is never stored (passes B/C and the next round's pass A recompute it from z1)
 inline bool lazy_edges(const mtmc_mpn_call* c) { return !c->training && c->n_edges > 2048 * 256; }
 
+// column blocks of this call's pass A: the layout has the index (table size, edge count) AND the call's own degree pays
+inline int call_col_blocks(const Ctx& x) {
+  if (x.lo.col_blocks <= 0) return 0;
+  return mtmc::plan_col_blocks(x.c->n_nodes, x.c->n_edges, avg_degree(x.c), x.c->training != 0) == x.lo.col_blocks ? x.lo.col_blocks : 0;
+}
+
 inline mtmc::RoundParams round_params(const Ctx& x, int r) {
   const mtmc_mpn_model* m = x.m;
   const int hn = (m->reattach_nodes ? 2 : 1) * MTMC_NODE_DIM;
@@ -315,6 +329,8 @@ inline mtmc::RoundParams round_params(const Ctx& x, int r) {
   p.deg = x.at<int>(x.lo.pub.deg_off); p.row_start = x.at<int>(x.lo.row_start); p.carry = x.at<float>(x.lo.carry);
   p.n_nodes = x.c->n_nodes;
   p.avg_degree = avg_degree(x.c);
+  p.col_blocks = call_col_blocks(x);
+  p.col_sub = x.at<int>(x.lo.col_sub); p.cb_row_lo = proj_lo(x.c); p.cb_row_hi = proj_hi(x.c);
   p.enc = enc_params(x);
   return p;
 }
@@ -333,6 +349,26 @@ inline bool use_staged(const Ctx& x, int l) {
 inline bool use_rows(const Ctx& x, int l) {
   return l >= 1 && !x.lo.training && mtmc::rows_layer(x.c->n_nodes, x.m->enc_node[l].in_dim, x.m->enc_node[l].out_dim) &&
          mtmc::rows_layer(x.c->node_hi - x.c->node_lo, x.m->enc_node[l].in_dim, x.m->enc_node[l].out_dim);
+}
+
+// Row panels of the pipelined layer 0: cuts[0..np] (multiples of the tile height), np <= kMaxPanels; *bm = the tile height
+// of every panel (what the whole matrix would pick).  One round = 256 workgroups = 256 / tiles_n row tiles.
+inline int l0_panels(int64_t rows, int Nout, int64_t* cuts, int* bm) {
+  const int tiles_n = (Nout + 255) / 256;
+  *bm = mtmc::presplit_tile_rows(rows, tiles_n);
+  const int64_t per_round = (int64_t)(256 / tiles_n > 0 ? 256 / tiles_n : 1) * *bm;
+  const int mode = mtmc::knobs().l0_pipeline;
+  int np = 0;
+  int64_t at = 0, k = 1;
+  cuts[0] = 0;
+  while (at < rows) {
+    int64_t take = per_round * (mode == 3 ? 2 : mode == 2 ? 1 : k);
+    if (np == kMaxPanels - 1 || at + take > rows) take = rows - at;
+    at += take;
+    cuts[++np] = at;
+    if (k < 8) k *= 2;
+  }
+  return np;
 }
 
 enum { kPhMemset = -1, kPhPrep = -2 };   // the two halves of MTMC_PH_BEGIN, for the forked forward
@@ -375,9 +411,14 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
                                     m->enc_node[l].in_dim, x.at<unsigned>(x.lo.amax_w) + l * mtmc::kAmaxRep, 0, 0};
         }
         mtmc::launch_prep(p, s);
+        if (L > 0 && c->n_edges > 0 && call_col_blocks(x) > 0) {   // sub-run boundaries of the column-blocked pass A, once per forward
+          const mtmc::RoundParams rp = round_params(x, 0);
+          mtmc::launch_colblock_index(rp, x.at<int>(x.lo.col_sub), rp.col_blocks, rp.cb_row_lo, rp.cb_row_hi, s);
+        }
         if (pre0) {     // instead of the |.|max of x and W0: their fp16 planes and row scales (one pass over each)
-          mtmc::launch_split_rows(c->x, c->x_row_stride, c->node_hi - c->node_lo, m->enc_node[0].in_dim, x.at<void>(x.lo.xh),
-                                  x.at<float>(x.lo.inv_a), s);
+          if (!x.pipe)  // (pipelined layer 0: the x planes are made panel by panel in MTMC_PH_NODE_ENC 0)
+            mtmc::launch_split_rows(c->x, c->x_row_stride, c->node_hi - c->node_lo, m->enc_node[0].in_dim, x.at<void>(x.lo.xh),
+                                    x.at<float>(x.lo.inv_a), s);
           if (!w_cached)
             mtmc::launch_split_rows(m->enc_node[0].weight, m->enc_node[0].in_dim, m->enc_node[0].out_dim,
                                     m->enc_node[0].in_dim, x.at<void>(x.lo.wh), x.at<float>(x.lo.inv_w), s);
@@ -409,6 +450,28 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
         q.stats_out = x.at<double>(x.lo.stat_enc_layer[0]);
         q.amax_y = x.at<unsigned>(x.lo.amax) + (1 + MTMC_MAX_ENC_LAYERS) * mtmc::kAmaxRep;
         q.M = rows; q.K = Lr.in_dim; q.Nout = Lr.out_dim;
+        if (x.pipe) {
+          // Row panels: the side stream splits panel after panel (HBM-bound), the main stream multiplies panel i as soon as
+          // its planes are there (matrix-bound): the split pass leaves the critical path except for the first panel.
+          // Panel = whole rounds of workgroups of the tile height the whole matrix would get, so no round is paid twice.
+          int64_t cuts[kMaxPanels + 1];
+          const int np = l0_panels(rows, Lr.out_dim, cuts, &q.bm);
+          q.M_rows = rows;
+          if (hipEventRecord(x.pipe->fork, s) != hipSuccess || hipStreamWaitEvent(x.pipe->stream, x.pipe->fork, 0) != hipSuccess)
+            return fail(MTMC_E_HIP, "encoder layer 0: fork onto the side stream failed");
+          for (int i = 0; i < np; ++i) {
+            mtmc::launch_split_rows_range(c->x, c->x_row_stride, rows, Lr.in_dim, x.at<void>(x.lo.xh), x.at<float>(x.lo.inv_a),
+                                          cuts[i], cuts[i + 1], x.pipe->stream);
+            if (hipEventRecord(x.pipe->ready[i], x.pipe->stream) != hipSuccess) return fail(MTMC_E_HIP, "hipEventRecord failed");
+          }
+          for (int i = 0; i < np; ++i) {               // (the wait on the last panel's event also joins the side stream)
+            if (hipStreamWaitEvent(s, x.pipe->ready[i], 0) != hipSuccess) return fail(MTMC_E_HIP, "hipStreamWaitEvent failed");
+            q.m_lo = cuts[i]; q.M = cuts[i + 1];
+            const int rc = mtmc::launch_gemm_presplit(q, s);
+            if (rc != 0) return fail(rc == MTMC_E_HIP ? MTMC_E_HIP : MTMC_E_ARG, "encoder layer 0: pre-split GEMM refused a panel");
+          }
+          break;
+        }
         const int rc = mtmc::launch_gemm_presplit(q, s);
         if (rc != 0) return fail(rc == MTMC_E_HIP ? MTMC_E_HIP : MTMC_E_ARG, "encoder layer 0: pre-split GEMM refused the shape or the launch");
         break;

@@ -80,8 +80,13 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepParams p) {
     }
     const int r = active ? (int)r64 : -1;
     int prev = __shfl_up(r, 1, 64);
-    if (lane == 0) prev = (active && e > 0) ? (int)p.row[(e - 1) * p.idx_stride] : r;
+    int64_t prev_c = __shfl_up(c64, 1, 64);
+    if (lane == 0) {
+      prev = (active && e > 0) ? (int)p.row[(e - 1) * p.idx_stride] : r;
+      prev_c = (active && e > 0) ? p.col[(e - 1) * p.idx_stride] : c64;
+    }
     if (active && prev > r) p.flags[0] = 1;               // rows not globally non-decreasing
+    if (active && prev == r && prev_c > c64) p.flags[2] = 1;   // columns not ascending inside a row (column-blocked pass A)
     if (active && (e == 0 || prev != r)) p.row_start[r] = (int)e;   // first edge of the row (meaningful when sorted)
     // out-degree: one atomic per run of equal rows inside the wave
     const bool head = active && (lane == 0 || prev != r);
@@ -204,12 +209,19 @@ struct EdgeIn { float4 pr, pc, ev; float a0, a1; };
 #endif
 
 template <int MODE>
+__device__ __forceinline__ void edge_load_rc(const RoundParams& p, int64_t e, int r, int col, EdgeIn& in);
+template <int MODE>
 __device__ __forceinline__ void edge_load(const RoundParams& p, int64_t e, EdgeIn& in) {
 #if PA_NT & 1
   const int r = __builtin_nontemporal_load(p.row32 + e), col = __builtin_nontemporal_load(p.col32 + e);
 #else
   const int r = p.row32[e], col = p.col32[e];
 #endif
+  edge_load_rc<MODE>(p, e, r, col, in);
+}
+// ... with the row / column ids in hand (the column-blocked traversal knows the row without loading it)
+template <int MODE>
+__device__ __forceinline__ void edge_load_rc(const RoundParams& p, int64_t e, int r, int col, EdgeIn& in) {
   // P = [Pr: N x 4 | Pc: N x 4]: the randomly gathered half is a compact 16 B/node table (four nodes per 64-byte sector)
   in.pr = *reinterpret_cast<const float4*>(p.P + (int64_t)r * 4);
   in.pc = *reinterpret_cast<const float4*>(p.P + ((int64_t)p.n_nodes + col) * 4);
@@ -290,6 +302,7 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 5 : 1)) void pass_a_kernel(RoundP
   __shared__ PrevAffine pa_s;
   EdgeConstsS ks;                                  // first thing in the kernel: ahead of every store and barrier these
   load_edge_consts_s<MODE>(p, ks);                 // uniform loads are scalar loads (SGPRs); behind one they become vector loads
+  if (p.col_blocks > 0 && p.flags[0] == 0 && p.flags[2] == 0) return;   // pass_a_blocked_kernel, launched just before, did this round
   if (p.lazy_e && !(MODE & 1)) {
     stat_gather(p.prev_stats + kRoundZ1Off, 8, kZ1Stride, red);
     __syncthreads();
@@ -346,6 +359,154 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 5 : 1)) void pass_a_kernel(RoundP
       edge_load<MODE>(p, e, in);
       finish(e, in);
     }
+  }
+  block_atomic_add<8>(acc, p.stats + kRoundZ1Off, kZ1Stride, red);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pass A by COLUMN BLOCKS (graphs whose Pc table outgrows an XCD's 4 MB L2: config 5, N = 1M -> 16 MB).
+// In edge order every 16-byte Pc[col] gather of such a graph misses the L2 and fetches a 64-byte sector of its own from the
+// Infinity Cache: 6.1 GB fetched for 2.4 GB of algorithmic reads per launch, 1.85 ms.  A row-sorted list
+// with ascending columns inside a row (the reference's lists are: inference.py:407-413 builds them as cartesian products
+// of ascending node lists) is also sorted by column INSIDE every row, so the edges of row i whose column falls into block b
+// are one contiguous sub-run [sub[i][b], sub[i][b+1]).  colblock_index_kernel finds the B - 1 inner boundaries of every row
+// once per forward (binary searches inside the row's own column segment); pass_a_blocked_kernel then walks
+// (256-row chunk) x (column block) pieces, the block bound to blockIdx % 8 -- under round-robin placement one XCD, whose L2
+// then serves all gathers from a 2 MB slice of Pc (placement changes speed only).  Per wave: 64 rows' sub-run lengths ->
+// inclusive scan -> every lane takes slots k, k + 64, ... of the wave's concatenated sub-runs and finds its row by a 6-step
+// binary search over the scan in LDS.  z1 lands where it always does (edge order in memory is unchanged), so passes B / C and
+// the next round are untouched.  prep_kernel's flags decide on the device: unsorted rows or columns -> this kernel returns
+// and pass_a_kernel, launched behind it, does the round (and vice versa).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colblock_index_kernel(const int* __restrict__ col32, const int* __restrict__ row_start,
+                                                             const int* __restrict__ deg, const int* __restrict__ flags,
+                                                             int64_t row_lo, int64_t row_hi, int B, int blk_nodes,
+                                                             int* __restrict__ sub) {
+  if (flags[0] != 0 || flags[2] != 0) return;
+  const int64_t n_items = (row_hi - row_lo) * (B + 1);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = row_lo + i / (B + 1);
+    const int b = (int)(i % (B + 1));
+    const int d = deg[r];
+    int pos = 0;
+    if (d > 0) {
+      const int s0 = row_start[r];
+      if (b == 0) pos = s0;
+      else if (b == B) pos = s0 + d;
+      else {                                                 // first edge of the row with col >= b * blk_nodes
+        const int want = b * blk_nodes;
+        int lo = s0, hi = s0 + d;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (col32[mid] < want) lo = mid + 1; else hi = mid;
+        }
+        pos = lo;
+      }
+    }
+    sub[(r - row_lo) * (B + 1) + b] = pos;                   // (a row without edges: all zeros -> empty sub-runs)
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, (MODE == 0 ? 4 : 1)) void pass_a_blocked_kernel(RoundParams p, const int* __restrict__ sub,
+                                                                                  int B, int64_t row_lo, int64_t row_hi) {
+  __shared__ EdgeConstsV cs_s;
+  __shared__ double red[8 * 4];
+  __shared__ PrevAffine pa_s;
+  __shared__ int pre_s[4][64], base_s[4][64];
+  EdgeConstsS ks;
+  load_edge_consts_s<MODE>(p, ks);
+  if (p.flags[0] != 0 || p.flags[2] != 0) return;   // unsorted rows / columns: pass_a_kernel does this round (block-uniform)
+  if (p.lazy_e && !(MODE & 1)) {
+    stat_gather(p.prev_stats + kRoundZ1Off, 8, kZ1Stride, red);
+    __syncthreads();
+    if (threadIdx.x < 4)
+      bn_affine(red[threadIdx.x], red[4 + threadIdx.x], p.e_total, p.ue_g[threadIdx.x], p.ue_bt[threadIdx.x],
+                pa_s.s[threadIdx.x], pa_s.t[threadIdx.x]);
+  }
+  stage_edge_consts<MODE>(p, &cs_s);
+  PrevAffine pa;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { pa.s[j] = pa_s.s[j]; pa.t[j] = pa_s.t[j]; }
+  EdgeConstsV c;
+  {
+    const float* src = reinterpret_cast<const float*>(&cs_s);
+    float* dst = reinterpret_cast<float*>(&c);
+#pragma unroll
+    for (int i = 0; i < kEdgeConstsV; ++i) dst[i] = MODE != 0 ? src[i] : 0.f;
+  }
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // column block of this workgroup: blockIdx % 8 picks the XCD-bound residue, the next bits the block among that XCD's B / 8
+  const int per_xcd = B >> 3;
+  const int b = (int)(blockIdx.x & 7) + 8 * (int)((blockIdx.x >> 3) % per_xcd);
+  const int64_t group = (blockIdx.x >> 3) / per_xcd, n_groups = (gridDim.x >> 3) / per_xcd;
+  const int64_t n_chunks = (row_hi - row_lo + 255) / 256;
+  constexpr int U = 4;                              // slots per lane and trip: four independent load chains in flight
+  for (int64_t chunk = group; chunk < n_chunks; chunk += n_groups) {
+    const int64_t r0 = row_lo + chunk * 256 + w * 64;          // this wave's 64 rows
+    const int64_t r = r0 + lane;
+    int s0 = 0, len = 0;
+    if (r < row_hi) {
+      const int* sb = sub + (r - row_lo) * (B + 1) + b;
+      s0 = sb[0];
+      len = sb[1] - s0;
+    }
+    int incl = len;                                   // inclusive scan over the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int up = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += up;
+    }
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    pre_s[w][lane] = incl;
+    base_s[w][lane] = s0 - (incl - len);              // edge index of slot k inside this row's sub-run: base + k
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int k0 = 0; k0 < total; k0 += 64 * U) {
+      EdgeIn in[U];
+      int64_t ee[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = k0 + u * 64 + lane;
+        ok[u] = k < total;
+        int j = 0;                                    // first row of the wave whose inclusive count exceeds k
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1)
+          if (pre_s[w][j + step - 1] <= k) j += step;
+        j = j > 63 ? 63 : j;
+        ee[u] = ok[u] ? (int64_t)base_s[w][j] + k : 0;
+        if (ok[u]) {
+#if PA_NT & 1
+          const int col = __builtin_nontemporal_load(p.col32 + ee[u]);
+#else
+          const int col = p.col32[ee[u]];
+#endif
+          edge_load_rc<MODE>(p, ee[u], (int)(r0 + j), col, in[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!ok[u]) continue;
+        float z[4];
+        edge_z1<MODE, false>(p, ks, c, pa, ee[u], in[u], z);
+        if ((PA_NT & 4) || p.stream_z1) {
+          typedef float f4v __attribute__((ext_vector_type(4)));
+          f4v zv = {z[0], z[1], z[2], z[3]};
+          __builtin_nontemporal_store(zv, reinterpret_cast<f4v*>(p.e_buf) + ee[u]);
+        } else {
+          reinterpret_cast<float4*>(p.e_buf)[ee[u]] = make_float4(z[0], z[1], z[2], z[3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          acc[k] += z[k];
+          acc[4 + k] += (double)z[k] * z[k];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();                  // (the next chunk overwrites this wave's LDS rows)
   }
   block_atomic_add<8>(acc, p.stats + kRoundZ1Off, kZ1Stride, red);
 }
@@ -1294,12 +1455,49 @@ static void launch_pass_a_mode(const RoundParams& p, hipStream_t s) {
     default: hipLaunchKernelGGL((pass_a_kernel<kPassAEpt, MODE, false>), dim3(edge_grid(p.n_edges, 256 * kPassAEpt)), dim3(256), 0, s, p);
   }
 }
+// Column-blocked pass A: when, and with how many blocks.  Only where the gathered table cannot live in an XCD's L2 anyway
+// (N * 16 B > 3 MB), on many-edge eval-mode lists whose sub-runs stay long enough to pay for their bookkeeping (average
+// degree >= 4 per column block).  Blocks of <= 2 MB of Pc, a multiple of 8 (one residue of blockIdx % 8 per block), <= 64.
+int plan_col_blocks(int64_t n_nodes, int64_t n_edges, double avg_degree, bool training) {
+  const Knobs& kn = knobs();
+  if (kn.no_col_blocks || training || n_edges <= kSmallEdges || n_nodes * 16 <= (int64_t)3 << 20 || n_nodes >= (1ll << 31) - 64) return 0;
+  int64_t B = (n_nodes * 16 + ((int64_t)2 << 20) - 1) / ((int64_t)2 << 20);
+  B = (B + 7) / 8 * 8;
+  if (B > 64) B = 64;
+  if (kn.col_blocks >= 8 && kn.col_blocks <= 64 && kn.col_blocks % 8 == 0) B = kn.col_blocks;
+  return avg_degree >= 4.0 * (double)B ? (int)B : 0;
+}
+void launch_colblock_index(const RoundParams& p, int* sub, int B, int64_t row_lo, int64_t row_hi, hipStream_t s) {
+  if (B <= 0 || row_hi <= row_lo) return;
+  const int blk_nodes = (int)((p.n_nodes + B - 1) / B);
+  const int64_t items = (row_hi - row_lo) * (B + 1), blocks = (items + 255) / 256;
+  hipLaunchKernelGGL(colblock_index_kernel, dim3((int)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, s, p.col32, p.row_start, p.deg,
+                     p.flags, row_lo, row_hi, B, blk_nodes, sub);
+}
+template <int MODE>
+static void launch_pass_a_blocked_mode(const RoundParams& p, hipStream_t s) {
+  const int B = p.col_blocks;
+  const int64_t n_chunks = (p.cb_row_hi - p.cb_row_lo + 255) / 256;
+  int64_t groups = 1024 / B;                         // 1024 workgroups: four per CU
+  if (groups > n_chunks) groups = n_chunks;
+  if (groups < 1) groups = 1;
+  hipLaunchKernelGGL((pass_a_blocked_kernel<MODE>), dim3((unsigned)(groups * B)), dim3(256), 0, s, p, p.col_sub, B, p.cb_row_lo, p.cb_row_hi);
+}
 void launch_pass_a(const RoundParams& p0, hipStream_t s) {
   RoundParams p = p0;
+  if (p.col_blocks > 0 && p.enc.drop.on) p.col_blocks = 0;
   // z1 (16 B / edge) is read by pass B, pass C and the next pass A: stored with the default policy it waits for them in the
   // 256 MB Infinity Cache; a z1 that does not fit there only pushes everything else out on its way (config 5: -2 % on the
   // edge passes with a streaming store, config 4: +2 %)
   p.stream_z1 = p.n_edges * 16 > (int64_t)256 << 20;
+  if (p.col_blocks > 0) {                    // (returns at once on unsorted rows / columns; pass_a_kernel then does the round)
+    switch ((p.first_round ? 1 : 0) | (p.reattach_edges ? 2 : 0)) {
+      case 0: launch_pass_a_blocked_mode<0>(p, s); break;
+      case 1: launch_pass_a_blocked_mode<1>(p, s); break;
+      case 2: launch_pass_a_blocked_mode<2>(p, s); break;
+      default: launch_pass_a_blocked_mode<3>(p, s);
+    }
+  }
   switch ((p.first_round ? 1 : 0) | (p.reattach_edges ? 2 : 0)) {
     case 0: launch_pass_a_mode<0>(p, s); break;
     case 1: launch_pass_a_mode<1>(p, s); break;

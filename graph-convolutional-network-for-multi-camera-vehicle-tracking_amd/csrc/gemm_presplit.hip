@@ -28,11 +28,13 @@ namespace mtmc {
 // K <= 2048, K % 8 == 0: a lane holds 8 consecutive floats per 256-column chunk.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ X, int64_t ld, int64_t rows, int K,
-                                                         _Float16* __restrict__ H, int64_t plane, float* __restrict__ inv) {
+                                                         _Float16* __restrict__ H, int64_t plane, float* __restrict__ inv,
+                                                         int64_t r_lo, int64_t r_hi) {
+  // rows [r_lo, r_hi) of the `rows` the planes are laid out for (r_lo even: a wave's two rows share 128-byte lines)
   const int lane = threadIdx.x & 63, l = lane & 31;
-  const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
-  const bool live = row < rows;
-  const float* src = X + (live ? row : rows - 1) * ld;
+  const int64_t row = r_lo + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+  const bool live = row < r_hi;
+  const float* src = X + (live ? row : r_hi - 1) * ld;
   float4 v[8][2];
   float m = 0.f;
 #pragma unroll
@@ -81,10 +83,15 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
   }
 }
 
-void launch_split_rows(const float* X, int64_t ld, int64_t rows, int K, void* H, float* inv, hipStream_t s) {
-  const int64_t blocks = (rows + 7) / 8;
+void launch_split_rows_range(const float* X, int64_t ld, int64_t rows, int K, void* H, float* inv, int64_t r_lo, int64_t r_hi,
+                             hipStream_t s) {
+  if (r_hi <= r_lo) return;
+  const int64_t blocks = (r_hi - r_lo + 7) / 8;
   hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, ld, rows, K,
-                     static_cast<_Float16*>(H), rows * (int64_t)K, inv);
+                     static_cast<_Float16*>(H), rows * (int64_t)K, inv, r_lo, r_hi);
+}
+void launch_split_rows(const float* X, int64_t ld, int64_t rows, int K, void* H, float* inv, hipStream_t s) {
+  launch_split_rows_range(X, ld, rows, K, H, inv, 0, rows, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -106,7 +113,8 @@ __global__ __launch_bounds__(512, 1) void gemm_f16p_m16_kernel(SplitGemmParams p
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int tm_idx = (slot / tiles_n) * 8 + xcd, tn_idx = slot % tiles_n;
   if (tm_idx >= tiles_m) return;
-  const int64_t m0 = (int64_t)tm_idx * bm;
+  const int64_t m0 = p.m_lo + (int64_t)tm_idx * bm;                 // (m_lo: first row of this launch's panel)
+  const int64_t Mt = p.M_rows > 0 ? p.M_rows : p.M;                 // rows the planes are laid out for
   const int n0 = tn_idx * BT;
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wid / 4, wn = wid % 4;
@@ -126,8 +134,8 @@ __global__ __launch_bounds__(512, 1) void gemm_f16p_m16_kernel(SplitGemmParams p
   const unsigned lds0 = (unsigned)(size_t)smem;
   const char* a_tile = reinterpret_cast<const char*>(p.Ah + m0 * BK);
   const char* w_tile = reinterpret_cast<const char*>(p.Wh + (int64_t)n0 * BK);
-  const int64_t a_plane = p.M * (int64_t)p.K * 2, w_plane = (int64_t)p.Nout * p.K * 2;
-  const int64_t a_kt = p.M * BK * 2, w_kt = (int64_t)p.Nout * BK * 2;
+  const int64_t a_plane = Mt * (int64_t)p.K * 2, w_plane = (int64_t)p.Nout * p.K * 2;
+  const int64_t a_kt = Mt * BK * 2, w_kt = (int64_t)p.Nout * BK * 2;
   auto issue = [&](int kt, int buf) {
     const unsigned st = lds0 + buf * STAGE + wid * 1024;
 #pragma unroll
@@ -315,10 +323,12 @@ int presplit_tile_rows(int64_t M, int tiles_n) {
 }
 
 int launch_gemm_presplit(const SplitGemmParams& p, hipStream_t s) {
-  if (p.K % 64 || p.K > 2048 || p.M < 1 || p.Nout < 1) return 1;
+  if (p.K % 64 || p.K > 2048 || p.M < 1 || p.Nout < 1 || p.m_lo < 0 || p.m_lo >= p.M || (p.m_lo & 15) ||
+      (p.M_rows > 0 && p.M_rows < p.M))
+    return 1;
   const int tiles_n = (p.Nout + 255) / 256;
-  const int bm = presplit_tile_rows(p.M, tiles_n);
-  const int tiles_m = (int)((p.M + bm - 1) / bm);
+  const int bm = (p.bm >= 144 && p.bm <= 256 && p.bm % 16 == 0) ? p.bm : presplit_tile_rows(p.M - p.m_lo, tiles_n);
+  const int tiles_m = (int)((p.M - p.m_lo + bm - 1) / bm);
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
   const size_t lds = (size_t)2 * 4 * 256 * 32 * 2;
   if (!allow_big_lds(reinterpret_cast<const void*>(gemm_f16p_m16_kernel), 160 * 1024)) return MTMC_E_HIP;

@@ -19,6 +19,11 @@ struct Knobs {
   bool gemm_no_f16;          // MTMC_GEMM_NO_F16: bf16x6 (large) / exact fp32 (few rows) instead of the fp16 split kernels
   bool gemm_no_presplit;     // MTMC_GEMM_NO_PRESPLIT: layer 0 of many-row graphs on the in-loop kernel
   bool gemm_no_staged;       // MTMC_GEMM_NO_STAGED: layers >= 1 of many-row graphs on the in-loop kernel
+  bool no_col_blocks;        // MTMC_NO_COL_BLOCKS: pass A in edge order everywhere (A/B of the column-blocked traversal)
+  int col_blocks;            // MTMC_COL_BLOCKS: number of column blocks (8..64, multiple of 8; 0 = from the table size)
+  int l0_pipeline;           // MTMC_L0_PIPELINE: layer 0 of many-row graphs in row panels, the operand split of panel i+1 on a
+                             // side stream beside panel i's GEMM.  0 = off (one split pass, one GEMM), 1 = panels of
+                             // 1, 2, 4, 8, 8, ... rounds of workgroups (default), 2 / 3 = uniform panels of 1 / 2 rounds
 };
 const Knobs& knobs();
 
@@ -65,6 +70,9 @@ struct RoundParams {
   // edges per SOURCE ROW of this call's edges: local edges / owned rows for a row-complete shard, E_total / N otherwise
   // (a shard's local edge count over the GLOBAL node count would send 8 ranks of config 5 to the slow walk)
   double avg_degree;
+  // column-blocked pass A (graphs whose Pc table outgrows the L2): col_blocks > 0 = number of column blocks, col_sub =
+  // int[(cb_row_hi - cb_row_lo)][col_blocks + 1] sub-run boundaries (colblock_index_kernel) of the call's source rows
+  int col_blocks = 0; const int* col_sub = nullptr; int64_t cb_row_lo = 0, cb_row_hi = 0;
   EdgeEncParams enc;
 };
 
@@ -123,6 +131,9 @@ struct SplitGemmParams {
   double* stats_out;                        // f64[2*Nout], accumulated atomically (or nullptr)
   unsigned* amax_y;                         // u32[kAmaxRep] (atomicMax) or nullptr
   int64_t M; int K; int Nout;
+  // a launch over the row PANEL [m_lo, M) of planes that hold M_rows rows (pipelined layer 0: the operand split of the next
+  // panel runs beside this panel's GEMM); defaults = the whole matrix.  bm: tile height to use (0 = chosen per launch)
+  int64_t m_lo = 0; int64_t M_rows = 0; int bm = 0;
 };
 // Encoder layers >= 1 of many-row graphs (gemm_staged.hip): A = raw outputs of the previous layer (its BatchNorm + ReLU
 // applied by producer waves on the way into LDS), W = the layer's weights pre-split by launch_split_rows.
@@ -143,6 +154,10 @@ int launch_gemm_staged(const StagedGemmParams& p, hipStream_t s);   // 0 ok, 1 u
 bool rows_layer(int64_t rows, int K, int Nout);
 int launch_gemm_rows(const GemmParams& p, hipStream_t s);          // 0 ok, 1 unsupported shape
 void launch_split_rows(const float* X, int64_t ld, int64_t rows, int K, void* H, float* inv, hipStream_t s);
+// rows [r_lo, r_hi) only, of planes laid out for `rows` rows (X points at row 0)
+void launch_split_rows_range(const float* X, int64_t ld, int64_t rows, int K, void* H, float* inv, int64_t r_lo, int64_t r_hi,
+                             hipStream_t s);
+int presplit_tile_rows(int64_t M, int tiles_n);       // tile height the layer-0 GEMM picks for M rows (144..256)
 // hipFuncAttributeMaxDynamicSharedMemorySize, once per (kernel, device); false when HIP refuses (gemm_bn.hip)
 bool allow_big_lds(const void* fn, int bytes);
 bool presplit_layer0(int64_t rows, int K, int Nout);   // many rows, K % 64 == 0, K <= 2048, not disabled (MTMC_GEMM_NO_PRESPLIT)
@@ -152,6 +167,8 @@ void launch_prep(const PrepParams& p, hipStream_t s);
 void launch_enc2(const EdgeEncParams& enc, const float* attr, int64_t n_edges, double e_total, double* stat_enc2,
                  hipStream_t s);
 void launch_pass_a(const RoundParams& p, hipStream_t s);
+int plan_col_blocks(int64_t n_nodes, int64_t n_edges, double avg_degree, bool training);   // 0 = pass A in edge order
+void launch_colblock_index(const RoundParams& p, int* sub, int B, int64_t row_lo, int64_t row_hi, hipStream_t s);
 void launch_pass_b(const RoundParams& p, hipStream_t s);
 void launch_pass_c(const RoundParams& p, hipStream_t s);
 // Which pass-C kernel a call takes (host-only decision, also behind mtmc_mpn_plan): 0 = the half-wave walk; 1 = the

@@ -24,6 +24,9 @@ static Knobs read_knobs() {
   k.gemm_no_f16 = on("MTMC_GEMM_NO_F16");
   k.gemm_no_presplit = on("MTMC_GEMM_NO_PRESPLIT");
   k.gemm_no_staged = on("MTMC_GEMM_NO_STAGED");
+  k.l0_pipeline = (int)num("MTMC_L0_PIPELINE", 1);
+  k.no_col_blocks = on("MTMC_NO_COL_BLOCKS");
+  k.col_blocks = (int)num("MTMC_COL_BLOCKS", 0);
   return k;
 }
 

@@ -228,6 +228,10 @@ typedef struct mtmc_mpn_plan {
                                                 the any-order matrix-core kernel (few-edge lists: alone; many-edge lists
                                                 of >= 2^24 global node rows: returns on unsorted rows like the sorted one) */
   double avg_degree;                         /* edges per source row the pass-C choice was made on                  */
+  int32_t pass_a_col_blocks;                 /* 0: pass A walks the edges in order; B > 0: by B column blocks, so that the
+                                                gathered projections Pc of a block stay in an XCD's L2 (graphs whose 16 B / node
+                                                table outgrows it; row-sorted lists with ascending columns -- decided on the
+                                                device, the in-order kernel is launched behind it)                     */
 } mtmc_mpn_plan;
 int32_t mtmc_mpn_plan_call(const mtmc_mpn_model* model, const mtmc_mpn_call* call, mtmc_mpn_plan* out);
 

@@ -92,3 +92,36 @@ def test_config5_full_size_against_fp64_oracle_on_device_and_properties():
                                          dtype=torch.float64)
         err = _compare(got, ora64["classified_edges"][0], h, oh64, "config 5")
     print(f"config 5 full size: max |logit - fp64 oracle (device)| = {err:.3e}")
+
+
+@pytest.mark.parametrize("over,unsort_cols", [
+    (dict(num_enc_steps=2, num_class_steps=2), False),                                   # first-round + later-round kernels
+    (dict(num_enc_steps=2, num_class_steps=1, reattach_initial_edges=True, reattach_initial_nodes=True), False),
+    (dict(num_enc_steps=2, num_class_steps=1), True),       # columns shuffled inside the rows: the in-order kernel must take over
+])
+def test_column_blocked_pass_a_regime(over, unsort_cols):
+    """Pass A by column blocks (csrc/edge_kernels.hip pass_a_blocked_kernel: graphs whose Pc table, 16 B per node, outgrows
+    an XCD's L2): 230 000 nodes / 9.2 M edges is the smallest size that takes it (8 blocks of 28 750 nodes, sub-runs of 5
+    edges -- ragged: many are empty) -- against the oracle's code run by torch on the device in fp64, every edge."""
+    from mtmc_mpn import _lib, engine
+    from oracle import mpn_oracle
+    torch.manual_seed(3)
+    params = mtmc_mpn.default_params(**over)
+    m = mtmc_mpn.MOTMPNet(copy.deepcopy(params), None, ARCH).eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    N, E = 230_000, 9_200_000
+    d = graphs.stress_graph(N, E // 2, seed=11, device="cuda")
+    plan = engine.ForwardEngine(m).plan(N, E)
+    assert plan.pass_a_col_blocks == 8 and plan.pass_c == _lib.PASS_C_MFMA_SORTED
+    if unsort_cols:                                          # same rows, columns of each row in random order
+        perm = torch.argsort(d.edge_index[0] * 4 + torch.randint(0, 4, (E,), device="cuda"), stable=True)
+        d.edge_index, d.edge_attr = d.edge_index[:, perm].contiguous(), d.edge_attr[perm].contiguous()
+        assert (d.edge_index[0][1:] >= d.edge_index[0][:-1]).all()
+    with torch.no_grad():
+        out, h = m.cuda()(d)
+        torch.cuda.synchronize()
+        sd_dev = {k: v.cuda() for k, v in sd.items()}
+        ora64, oh64 = mpn_oracle.forward(sd_dev, copy.deepcopy(params), ARCH, d.x, d.edge_index, d.edge_attr,
+                                         dtype=torch.float64)
+        for i, got in enumerate(out["classified_edges"]):
+            _compare(got, ora64["classified_edges"][i], h, oh64, f"column-blocked pass A, output {i}")

@@ -25,6 +25,7 @@ N5, E5 = 1_000_000, 100_000_000          # BASELINE config 5
 def test_config5_shards_take_the_whole_graphs_kernels(eng, world):
     whole = eng.plan(N5, E5)
     assert whole.pass_c == _lib.PASS_C_MFMA_SORTED and whole.lazy_edges and whole.edges_per_thread == 4
+    assert whole.pass_a_col_blocks == 8      # 16 MB of column projections: pass A by 2 MB column blocks (one per XCD)
     assert whole.enc_kernel == [_lib.GEMM_PRESPLIT_256, _lib.GEMM_STAGED_128, _lib.GEMM_STAGED_128, _lib.GEMM_ROWS_16]
     rows = mdist.even_ranges(N5, world)
     edges = mdist.even_ranges(E5, world)
@@ -39,6 +40,7 @@ def test_config5_shards_take_the_whole_graphs_kernels(eng, world):
         for p in (own, gen):
             assert p.pass_c == whole.pass_c, f"rank {r}/{world} left the matrix-core pass C"
             assert p.lazy_edges == whole.lazy_edges and p.edges_per_thread == whole.edges_per_thread
+            assert p.pass_a_col_blocks == whole.pass_a_col_blocks, f"rank {r}/{world} left the column-blocked pass A"
             assert p.enc_kernel == whole.enc_kernel and p.enc_split_k == whole.enc_split_k
 
 
@@ -60,6 +62,9 @@ def test_single_gpu_regimes(eng):
     assert trk.pass_c == _lib.PASS_C_MFMA_SORTED and trk.lazy_edges and trk.edges_per_thread == 4
     cfg4 = eng.plan(100_000, 10_000_000)
     assert cfg4.enc_kernel[0] == _lib.GEMM_PRESPLIT_256 and cfg4.pass_c == _lib.PASS_C_MFMA_SORTED
+    assert cfg4.pass_a_col_blocks == 0 and s02.pass_a_col_blocks == 0      # 1.6 MB of Pc fit an XCD's L2: edge order
+    assert eng.plan(1_000_000, 20_000_000).pass_a_col_blocks == 0          # 20 edges per row: sub-runs too short for 8 blocks
+    assert eng.plan(1_000_000, 100_000_000, training=True).pass_a_col_blocks == 0
     det = eng.plan(100_000, 10_000_000, flags=_lib.F_DETERMINISTIC)
     assert det.pass_c == _lib.PASS_C_MFMA_SORTED        # many edges: the sorted kernel's fixed-order variant (no atomics)
     det_small = eng.plan(450, 150_454, flags=_lib.F_DETERMINISTIC)
