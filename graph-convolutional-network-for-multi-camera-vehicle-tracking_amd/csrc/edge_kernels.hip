@@ -443,15 +443,23 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 4 : 1)) void pass_a_blocked_kerne
   const int64_t group = (blockIdx.x >> 3) / per_xcd, n_groups = (gridDim.x >> 3) / per_xcd;
   const int64_t n_chunks = (row_hi - row_lo + 255) / 256;
   constexpr int U = 4;                              // slots per lane and trip: four independent load chains in flight
-  for (int64_t chunk = group; chunk < n_chunks; chunk += n_groups) {
-    const int64_t r0 = row_lo + chunk * 256 + w * 64;          // this wave's 64 rows
-    const int64_t r = r0 + lane;
-    int s0 = 0, len = 0;
-    if (r < row_hi) {
+  // a lane's row of the chunk: its sub-run [s0, s0 + len) of column block b.  The NEXT chunk's pair is requested before this
+  // chunk's edges are walked (a dependent global load at the head of every ~800-edge chunk would idle the wave for its latency)
+  auto sub_of = [&](int64_t chunk, int& s0, int& len) {
+    const int64_t r = row_lo + chunk * 256 + w * 64 + lane;
+    s0 = 0; len = 0;
+    if (chunk < n_chunks && r < row_hi) {
       const int* sb = sub + (r - row_lo) * (B + 1) + b;
       s0 = sb[0];
       len = sb[1] - s0;
     }
+  };
+  int s0_n, len_n;
+  sub_of(group, s0_n, len_n);
+  for (int64_t chunk = group; chunk < n_chunks; chunk += n_groups) {
+    const int64_t r0 = row_lo + chunk * 256 + w * 64;          // this wave's 64 rows
+    const int s0 = s0_n, len = len_n;
+    sub_of(chunk + n_groups, s0_n, len_n);
     int incl = len;                                   // inclusive scan over the wave
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -465,44 +473,53 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 4 : 1)) void pass_a_blocked_kerne
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int k0 = 0; k0 < total; k0 += 64 * U) {
+      // Branch-free up to the stores: slots past the wave's total are clamped to its last slot (loaded and computed again,
+      // never stored or counted), so that the U searches, then the U column loads, then the U x 3 data loads are each in flight
+      // together -- behind a per-slot `if` every slot's chain (search -> column id -> gather) would run after the previous one's
       EdgeIn in[U];
       int64_t ee[U];
+      int rw[U], cl[U];
       bool ok[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int k = k0 + u * 64 + lane;
+        int k = k0 + u * 64 + lane;
         ok[u] = k < total;
+        k = ok[u] ? k : total - 1;
         int j = 0;                                    // first row of the wave whose inclusive count exceeds k
 #pragma unroll
         for (int step = 32; step > 0; step >>= 1)
           if (pre_s[w][j + step - 1] <= k) j += step;
-        j = j > 63 ? 63 : j;
-        ee[u] = ok[u] ? (int64_t)base_s[w][j] + k : 0;
-        if (ok[u]) {
-#if PA_NT & 1
-          const int col = __builtin_nontemporal_load(p.col32 + ee[u]);
-#else
-          const int col = p.col32[ee[u]];
-#endif
-          edge_load_rc<MODE>(p, ee[u], (int)(r0 + j), col, in[u]);
-        }
+        ee[u] = (int64_t)base_s[w][j] + k;
+        rw[u] = (int)(r0 + j);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (!ok[u]) continue;
+#if PA_NT & 1
+        cl[u] = __builtin_nontemporal_load(p.col32 + ee[u]);
+#else
+        cl[u] = p.col32[ee[u]];
+#endif
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) edge_load_rc<MODE>(p, ee[u], rw[u], cl[u], in[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
         float z[4];
         edge_z1<MODE, false>(p, ks, c, pa, ee[u], in[u], z);
-        if ((PA_NT & 4) || p.stream_z1) {
-          typedef float f4v __attribute__((ext_vector_type(4)));
-          f4v zv = {z[0], z[1], z[2], z[3]};
-          __builtin_nontemporal_store(zv, reinterpret_cast<f4v*>(p.e_buf) + ee[u]);
-        } else {
-          reinterpret_cast<float4*>(p.e_buf)[ee[u]] = make_float4(z[0], z[1], z[2], z[3]);
+        if (ok[u]) {
+          if ((PA_NT & 4) || p.stream_z1) {
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            f4v zv = {z[0], z[1], z[2], z[3]};
+            __builtin_nontemporal_store(zv, reinterpret_cast<f4v*>(p.e_buf) + ee[u]);
+          } else {
+            reinterpret_cast<float4*>(p.e_buf)[ee[u]] = make_float4(z[0], z[1], z[2], z[3]);
+          }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          acc[k] += z[k];
-          acc[4 + k] += (double)z[k] * z[k];
+          const float zk = ok[u] ? z[k] : 0.f;
+          acc[k] += zk;
+          acc[4 + k] += (double)zk * zk;
         }
       }
     }

@@ -188,6 +188,10 @@ class MOTMPNet(nn.Module):
         flags = (_lib_flags.F_DETERMINISTIC if self.deterministic else 0) | \
             (torch_ops.CHECK_INDICES if self.check_indices else 0) | \
             (0 if self.cache_weight_planes else torch_ops.NO_WEIGHT_CACHE)
-        logits, h, _ = torch.ops.mtmc_mpn.mp_forward(x, edge_index, edge_attr, params, self._config_key,
-                                                     self.training, seed, flags, tape)
+        if tape and edge_index.is_cuda and edge_attr.is_cuda and not torch.compiler.is_compiling():
+            # grad mode: the op's own forward / backward functions without the dispatcher around them (torch_ops._MpForwardLean)
+            logits, h = torch_ops.mp_forward_lean(x, edge_index, edge_attr, params, self._config_key, self.training, seed, flags)
+        else:
+            logits, h, _ = torch.ops.mtmc_mpn.mp_forward(x, edge_index, edge_attr, params, self._config_key,
+                                                         self.training, seed, flags, tape)
         return {"classified_edges": list(logits.unbind(0))}, h

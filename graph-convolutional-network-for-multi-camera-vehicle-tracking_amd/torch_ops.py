@@ -112,7 +112,6 @@ def _n_out(spec):
 # ---------------------------------------------------------------------------------------------------------------
 # the forward
 # ---------------------------------------------------------------------------------------------------------------
-@torch.library.impl("mtmc_mpn::mp_forward", "CUDA")
 def _mp_forward(x, edge_index, edge_attr, params, config, training, seed, flags, tape):
     eng = engine_for(config)
     eng.flags = int(flags) & 0xFFFF
@@ -130,6 +129,9 @@ def _mp_forward(x, edge_index, edge_attr, params, config, training, seed, flags,
     return prep.logits, prep.h, (prep.ws if tape else prep.ws.new_empty(0))
 
 
+torch.library.impl("mtmc_mpn::mp_forward", "CUDA")(_mp_forward)   # (call form: the decorator does not return the function)
+
+
 @torch.library.register_fake("mtmc_mpn::mp_forward")
 def _mp_forward_fake(x, edge_index, edge_attr, params, config, training, seed, flags, tape):
     eng = engine_for(config)
@@ -143,7 +145,6 @@ def _mp_forward_fake(x, edge_index, edge_attr, params, config, training, seed, f
             x.new_empty((tape_bytes,), dtype=torch.uint8))
 
 
-@torch.library.impl("mtmc_mpn::mp_backward", "CUDA")
 def _mp_backward(tape, x, edge_index, edge_attr, params, config, training, seed, flags, d_logits, d_h, need_x, need_attr):
     eng = engine_for(config)
     eng.flags = int(flags) & 0xFFFF
@@ -168,6 +169,9 @@ def _mp_backward(tape, x, edge_index, edge_attr, params, config, training, seed,
             C.byref(prep.model), C.byref(prep.call), steps, dh.data_ptr() if dh is not None else None,
             flat.data_ptr(), flat.numel(), dx.data_ptr() if need_x else None, dattr.data_ptr() if need_attr else None))
     return flat, dx, dattr
+
+
+torch.library.impl("mtmc_mpn::mp_backward", "CUDA")(_mp_backward)
 
 
 @torch.library.register_fake("mtmc_mpn::mp_backward")
@@ -210,6 +214,46 @@ def _autograd_backward(ctx, d_logits, d_h, _d_tape):
 
 
 torch.library.register_autograd("mtmc_mpn::mp_forward", _autograd_backward, setup_context=_setup_context)
+
+
+class _MpForwardLean(torch.autograd.Function):
+    """The same forward / backward pair as the registered op's autograd formula -- `_mp_forward` and `_mp_backward` are the
+    functions registered as its kernels -- called without the dispatcher around them.  With 34 parameter tensors in a
+    `Tensor[]` argument torch.library's autograd wrapper (pytree flattening, a second Function.apply, redispatch) costs the
+    host about 0.2 ms per forward and as much again per backward (tools/train_cpu_profile.py), on a training step whose
+    kernels take 0.7 ms: `MOTMPNet.forward` uses this path under grad mode (reference train.py:356,424); eval-mode calls and
+    every functional user go through `torch.ops.mtmc_mpn.mp_forward`."""
+
+    @staticmethod
+    def forward(ctx, x, edge_index, edge_attr, config, training, seed, flags, *params):
+        logits, h, tape = _mp_forward(x, edge_index, edge_attr, params, config, training, seed, flags, True)
+        ctx.config, ctx.training, ctx.seed, ctx.flags = config, training, seed, flags
+        ctx.need_x, ctx.need_attr = x.requires_grad, edge_attr.requires_grad
+        ctx.tape = tape                      # (not an input or output: kept on the context; read-only for the backward's purposes)
+        ctx.save_for_backward(x, edge_index, edge_attr, *params)
+        return logits, h
+
+    @staticmethod
+    def backward(ctx, d_logits, d_h):
+        x, edge_index, edge_attr, *params = ctx.saved_tensors
+        flat, dx, dattr = _mp_backward(ctx.tape, x, edge_index, edge_attr, params, ctx.config, ctx.training, ctx.seed, ctx.flags,
+                                       d_logits, d_h, ctx.need_x, ctx.need_attr)
+        spec = engine_for(ctx.config).spec
+        layout, _ = grad_layout(spec)
+        grads = [flat[o:o + n].view(shp) for o, n, shp in layout]
+        if spec.num_enc_steps == 0:           # the update MLPs took no part: None, as autograd gives the reference
+            i = 0
+            for slot, _, layer in _layer_slots(spec):
+                k = 4 if layer.bn_slot is not None else 2
+                if slot in ("upd_edge", "upd_node"):
+                    grads[i:i + k] = [None] * k
+                i += k
+        return (dx if ctx.need_x else None, None, dattr if ctx.need_attr else None, None, None, None, None, *grads)
+
+
+def mp_forward_lean(x, edge_index, edge_attr, params, config, training, seed, flags):
+    """(logits [S,E,C], h [N,32]) with autograd, for CUDA tensors: see _MpForwardLean."""
+    return _MpForwardLean.apply(x, edge_index, edge_attr, config, training, seed, flags, *params)
 
 
 # ---------------------------------------------------------------------------------------------------------------
