@@ -317,6 +317,8 @@ def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
     # dominant kernel = the kernel NAME with the largest summed time (all its launches in a step, the same
     # granularity as a rocprofv3 --stats row); phases that launched nothing (un-split combine) are skipped
     enc_names = encoder_kernels(model, n, e)
+    from mtmc_mpn import engine as _engine
+    plan = (model._engine or _engine.ForwardEngine(model)).plan(n, e)     # which kernels the library runs for this size
 
     def kernel_of(ph, arg):
         return enc_names[arg] if ph == _lib.PH_NODE_ENC else PHASE_NAMES[ph]
@@ -366,7 +368,11 @@ def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
            "roofline": roofline,
            "forward_algorithmic": {"bytes": b_fwd, "GBps": b_fwd / sec / 1e9, "frac_of_hbm_peak": b_fwd / sec / 1e9 / HBM_PEAK_GBS,
                                    "note": "SURVEY 8(d) reference-formulation bytes / whole-forward time"},
-           "phase_ms_sum": sum(ms), "phase_ms": {k: round(v, 4) for k, v in phases.items()}}
+           "phase_ms_sum": sum(ms), "phase_ms": {k: round(v, 4) for k, v in phases.items()},
+           "plan": {"encoder_kernels": enc_names, "enc_split_k": plan.enc_split_k, "edges_per_thread": plan.edges_per_thread,
+                    "lazy_edges": plan.lazy_edges, "pass_c": ["walk", "mfma_sorted", "mfma_any"][plan.pass_c],
+                    "pass_a_col_blocks": plan.pass_a_col_blocks,
+                    "layer0_pipeline": os.environ.get("MTMC_L0_PIPELINE", "1 (default: row panels, split on a side stream)")}}
     if with_cpu:
         sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
         res["cpu_baseline"] = cpu_baseline(name, params, sd, data)

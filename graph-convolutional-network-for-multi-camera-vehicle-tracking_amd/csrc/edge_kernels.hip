@@ -13,6 +13,8 @@
 //   classify_e0_kernel logits of the encoded edges when L == 0                      (mpn.py:295-297)
 #include "kernels.h"
 
+#include <type_traits>
+
 namespace mtmc {
 
 // ------------------------------------------------------------------------------------------------
@@ -472,16 +474,19 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 4 : 1)) void pass_a_blocked_kerne
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int k0 = 0; k0 < total; k0 += 64 * U) {
-      // Branch-free up to the stores: slots past the wave's total are clamped to its last slot (loaded and computed again,
-      // never stored or counted), so that the U searches, then the U column loads, then the U x 3 data loads are each in flight
-      // together -- behind a per-slot `if` every slot's chain (search -> column id -> gather) would run after the previous one's
-      EdgeIn in[U];
-      int64_t ee[U];
-      int rw[U], cl[U];
-      bool ok[U];
+    // Branch-free up to the stores: slots past the wave's total are clamped to its last slot (loaded and computed again,
+    // never stored or counted), so that the UU searches, then the UU column loads, then the UU x 3 data loads are each in
+    // flight together -- behind a per-slot `if` every slot's chain (search -> column id -> gather) would run after the
+    // previous one's.  Whole trips of U x 64 slots take UU = U; what is left takes single 64-slot trips (a wave's ~800 slots
+    // are 3 whole trips + 32: one clamped trip of four would redo a fifth of the work).
+    auto trip = [&](int k0, auto uu_tag) {
+      constexpr int UU = decltype(uu_tag)::value;
+      EdgeIn in[UU];
+      int64_t ee[UU];
+      int rw[UU], cl[UU];
+      bool ok[UU];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < UU; ++u) {
         int k = k0 + u * 64 + lane;
         ok[u] = k < total;
         k = ok[u] ? k : total - 1;
@@ -493,7 +498,7 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 4 : 1)) void pass_a_blocked_kerne
         rw[u] = (int)(r0 + j);
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < UU; ++u) {
 #if PA_NT & 1
         cl[u] = __builtin_nontemporal_load(p.col32 + ee[u]);
 #else
@@ -501,9 +506,9 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 4 : 1)) void pass_a_blocked_kerne
 #endif
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) edge_load_rc<MODE>(p, ee[u], rw[u], cl[u], in[u]);
+      for (int u = 0; u < UU; ++u) edge_load_rc<MODE>(p, ee[u], rw[u], cl[u], in[u]);
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < UU; ++u) {
         float z[4];
         edge_z1<MODE, false>(p, ks, c, pa, ee[u], in[u], z);
         if (ok[u]) {
@@ -522,7 +527,10 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 4 : 1)) void pass_a_blocked_kerne
           acc[4 + k] += (double)zk * zk;
         }
       }
-    }
+    };
+    int k0 = 0;
+    for (; k0 + 64 * U <= total; k0 += 64 * U) trip(k0, std::integral_constant<int, U>());
+    for (; k0 < total; k0 += 64) trip(k0, std::integral_constant<int, 1>());
     __builtin_amdgcn_wave_barrier();                  // (the next chunk overwrites this wave's LDS rows)
   }
   block_atomic_add<8>(acc, p.stats + kRoundZ1Off, kZ1Stride, red);

@@ -112,7 +112,8 @@ def _n_out(spec):
 # ---------------------------------------------------------------------------------------------------------------
 # the forward
 # ---------------------------------------------------------------------------------------------------------------
-def _mp_forward(x, edge_index, edge_attr, params, config, training, seed, flags, tape):
+def _forward_prep(x, edge_index, edge_attr, params, config, training, seed, flags, tape):
+    """One forward: returns the prepared call (structs, outputs, workspace = tape)."""
     eng = engine_for(config)
     eng.flags = int(flags) & 0xFFFF
     eng.weight_cache = not (int(flags) & NO_WEIGHT_CACHE)
@@ -126,6 +127,11 @@ def _mp_forward(x, edge_index, edge_attr, params, config, training, seed, flags,
             bits = prep.ws[lay.flags_off:lay.flags_off + 32].view(torch.int32).cpu()
             if int(bits[1]) != 0:
                 raise IndexError("mtmc_mpn: edge_index holds node ids outside [0, N)")
+    return prep
+
+
+def _mp_forward(x, edge_index, edge_attr, params, config, training, seed, flags, tape):
+    prep = _forward_prep(x, edge_index, edge_attr, params, config, training, seed, flags, tape)
     return prep.logits, prep.h, (prep.ws if tape else prep.ws.new_empty(0))
 
 
@@ -145,13 +151,16 @@ def _mp_forward_fake(x, edge_index, edge_attr, params, config, training, seed, f
             x.new_empty((tape_bytes,), dtype=torch.uint8))
 
 
-def _mp_backward(tape, x, edge_index, edge_attr, params, config, training, seed, flags, d_logits, d_h, need_x, need_attr):
+def _mp_backward(tape, x, edge_index, edge_attr, params, config, training, seed, flags, d_logits, d_h, need_x, need_attr,
+                 prep=None):
+    """prep: the forward's prepared call (the lean autograd path keeps it: same tensors, same structs); None: rebuilt."""
     eng = engine_for(config)
     eng.flags = int(flags) & 0xFFFF
     spec = eng.spec
-    prep = eng.prepare(x, edge_index, edge_attr, tape=True, seed=seed, params=list(params), tape_ws=tape)
-    if not training:
-        prep.model.dropout_enc = prep.model.dropout_upd_edge = prep.model.dropout_upd_node = 0.0
+    if prep is None:
+        prep = eng.prepare(x, edge_index, edge_attr, tape=True, seed=seed, params=list(params), tape_ws=tape)
+        if not training:
+            prep.model.dropout_enc = prep.model.dropout_upd_edge = prep.model.dropout_upd_node = 0.0
     dev = prep.dev
     _, total = grad_layout(spec)                          # == mtmc_mpn_grad_layout (tests/test_torch_ops_registration.py)
     flat = torch.empty(total, dtype=torch.float32, device=dev)
@@ -226,18 +235,18 @@ class _MpForwardLean(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, edge_index, edge_attr, config, training, seed, flags, *params):
-        logits, h, tape = _mp_forward(x, edge_index, edge_attr, params, config, training, seed, flags, True)
+        prep = _forward_prep(x, edge_index, edge_attr, params, config, training, seed, flags, True)
         ctx.config, ctx.training, ctx.seed, ctx.flags = config, training, seed, flags
         ctx.need_x, ctx.need_attr = x.requires_grad, edge_attr.requires_grad
-        ctx.tape = tape                      # (not an input or output: kept on the context; read-only for the backward's purposes)
+        ctx.prep = prep                      # the call structs + the workspace (= tape): the backward runs on the very same call
         ctx.save_for_backward(x, edge_index, edge_attr, *params)
-        return logits, h
+        return prep.logits, prep.h
 
     @staticmethod
     def backward(ctx, d_logits, d_h):
         x, edge_index, edge_attr, *params = ctx.saved_tensors
-        flat, dx, dattr = _mp_backward(ctx.tape, x, edge_index, edge_attr, params, ctx.config, ctx.training, ctx.seed, ctx.flags,
-                                       d_logits, d_h, ctx.need_x, ctx.need_attr)
+        flat, dx, dattr = _mp_backward(ctx.prep.ws, x, edge_index, edge_attr, params, ctx.config, ctx.training, ctx.seed, ctx.flags,
+                                       d_logits, d_h, ctx.need_x, ctx.need_attr, prep=ctx.prep)
         spec = engine_for(ctx.config).spec
         layout, _ = grad_layout(spec)
         grads = [flat[o:o + n].view(shp) for o, n, shp in layout]
