@@ -84,27 +84,33 @@ def committed_rounds():
     return sorted({m.group(0) for m in (re.match(r"r\d\d", f) for f in names) if m}, reverse=True)
 
 
-def pmc_traffic(workload, kernel):
+def pmc_traffic(workload, kernel, launches_per_step=None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summaries (profiles/rNN_<workload>_pmc_*.txt,
     made by tools/pmc_summary.py from separate FETCH_SIZE and WRITE_SIZE passes of tools/fwd_loop.py on the same
     workload).  Units are KB; on gfx950 FETCH_SIZE counts wide (16 B/lane) streaming reads at one half
-    (MI355X_MICROARCH.md, HBM), so reads are doubled; WRITE_SIZE is exact.  None when no summary is committed."""
+    (MI355X_MICROARCH.md, HBM), so reads are doubled; WRITE_SIZE is exact.  None when no summary is committed.
+    `launches_per_step`: the kernel's launches per forward in the timing this is reported beside -- the profiled forward
+    may cut the same work into more launches (layer 0 in row panels): all of a forward's launches are added up (forwards
+    profiled = launches of prep_kernel) and divided by it, so that `traffic` and `achieved` are for the same unit of work."""
     tot = {}
     rnd = pmc_round(workload)
     if rnd is None:
         return None
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{workload}_pmc_{ctr}.txt")
-        num = den = 0.0
+        num = den = forwards = 0.0
         for line in open(path):
             parts = line.split()
-            if len(parts) >= 5 and parts[0].startswith(kernel) and ctr in parts:
+            if len(parts) >= 5 and ctr in parts:
                 calls, avg = float(parts[-2]), float(parts[-1])
-                num += calls * avg
-                den += calls
+                if parts[0].startswith(kernel):
+                    num += calls * avg
+                    den += calls
+                if parts[0].startswith("prep_kernel"):
+                    forwards += calls
         if den == 0:
             return None
-        tot[ctr] = num / den
+        tot[ctr] = num / (forwards * launches_per_step) if (launches_per_step and forwards) else num / den
     return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0
 
 
@@ -351,7 +357,7 @@ def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
                 "algorithmic_per_launch": work, "event_pair_floor_ms": empty_event_pair_ms()}
     if peak_note:
         roofline["peak_note"] = peak_note
-    roofline["traffic"] = pmc_traffic(name, dom_key)
+    roofline["traffic"] = pmc_traffic(name, dom_key, len(launches))
     if roofline["traffic"] is not None:
         roofline["traffic_note"] = ("HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/%s_%s_pmc_*.txt "
                                     "(separate rocprofv3 --pmc passes; gfx950 half-count correction on reads)"
