@@ -75,7 +75,8 @@ STAT_REPLICAS, ATTR_STRIDE, ENC2_STRIDE, Z1_STRIDE, M_STRIDE, Z2_STRIDE = 16, 16
 ROUND_BLOCK = STAT_REPLICAS * (Z1_STRIDE + M_STRIDE + Z2_STRIDE)
 F_DETERMINISTIC, F_GLOBAL_DEG, F_FORK, F_WEIGHTS_CACHED = 1, 4, 2, 8
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmtmc_mpn.so")
+# MTMC_MPN_LIB: another build of the same ABI (same-box A/B of two library versions, tools/lib_ab.sh); default: the in-tree build
+LIB_PATH = os.environ.get("MTMC_MPN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmtmc_mpn.so")
 EXPORTS = ["mtmc_mpn_abi_version", "mtmc_mpn_last_error", "mtmc_mpn_workspace_bytes", "mtmc_mpn_workspace_layout",
            "mtmc_mpn_forward", "mtmc_mpn_run_phase", "mtmc_mpn_run_phases", "mtmc_mpn_plan_call", "mtmc_scatter_add", "mtmc_scatter_add_i64", "mtmc_scatter_mean", "mtmc_scatter_max",
            "mtmc_mlp_layer_forward", "mtmc_mpn_train_workspace_bytes", "mtmc_mpn_backward", "mtmc_graph_workspace_bytes",

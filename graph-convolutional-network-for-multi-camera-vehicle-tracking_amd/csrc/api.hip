@@ -151,7 +151,8 @@ int32_t mtmc_mpn_forward(const mtmc_mpn_model* model, const mtmc_mpn_call* call)
     if (hipEventRecord(sd->join, sd->stream) != hipSuccess) return fail(MTMC_E_HIP, "hipEventRecord failed");
   } else {
     if ((rc = run_phase(x, MTMC_PH_BEGIN, 0))) return rc;
-    if ((rc = run_phase(x, MTMC_PH_EDGE_ENC, 0))) return rc;
+    x.enc2_rides = enc2_can_ride(x);              // few-row graphs: enc2 as passenger of the last encoder layer's launch
+    if (!x.enc2_rides && (rc = run_phase(x, MTMC_PH_EDGE_ENC, 0))) return rc;
   }
   for (int l = 0; l < model->n_enc_layers; ++l) {
     if ((rc = run_phase(x, MTMC_PH_NODE_ENC, l))) return rc;

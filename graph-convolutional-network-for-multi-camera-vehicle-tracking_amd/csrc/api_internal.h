@@ -97,7 +97,7 @@ inline void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* l
   for (int l = 0; l < m->n_enc_layers; ++l) lo->pub.stat_enc_layer_off[l] = lo->stat_enc_layer[l];
   lo->pub.stat_round_off = take((size_t)(L > 0 ? L : 1) * mtmc::kRoundBlock * sizeof(double));
   lo->pub.deg_off = take((size_t)N * sizeof(int32_t));
-  lo->pub.seg_off = take((size_t)N * 4 * sizeof(double));
+  lo->pub.seg_off = take(mtmc::fold_node_stat(E) ? 0 : (size_t)N * 4 * sizeof(double));   // (few-edge lists: none)
   lo->amax = take((size_t)(1 + 2 * MTMC_MAX_ENC_LAYERS) * mtmc::kAmaxRep * sizeof(uint32_t));
   lo->amax_w = take((size_t)MTMC_MAX_ENC_LAYERS * mtmc::kAmaxRep * sizeof(uint32_t));
   lo->pub.zero_bytes = off;
@@ -196,6 +196,8 @@ struct Ctx {
   char* ws;
   hipStream_t stream;
   const SidePipe* pipe = nullptr;    // set by mtmc_mpn_forward: layer 0 runs in row panels (split of panel i+1 beside GEMM i)
+  bool enc2_rides = false;           // set by mtmc_mpn_forward (few-row graphs): MTMC_PH_EDGE_ENC's work rides as passenger
+                                     // workgroups in the last node-encoder layer's GEMM launch instead of a launch of its own
   template <typename T> T* at(size_t off) const { return reinterpret_cast<T*>(ws + off); }
 };
 
@@ -308,6 +310,7 @@ inline mtmc::RoundParams round_params(const Ctx& x, int r) {
   p.drop_e = make_drop(x, m->dropout_upd_edge); p.drop_n = make_drop(x, m->dropout_upd_node);
   p.drop_stream = mtmc::kDropRound + 2 * r;
   p.P = round_P(x, r); p.Q = round_Q(x, r);
+  p.seg = x.at<double>(x.lo.pub.seg_off); p.fold_z2 = mtmc::fold_node_stat(x.c->n_edges) ? 1 : 0;
   p.ue_w = m->upd_edge.weight; p.ue_b = m->upd_edge.bias; p.ue_g = m->upd_edge.gamma; p.ue_bt = m->upd_edge.beta;
   p.ue_ld = m->upd_edge.in_dim; p.ue_eoff = 2 * hn;
   p.un_w = m->upd_node.weight; p.un_b = m->upd_node.bias; p.un_g = m->upd_node.gamma; p.un_bt = m->upd_node.beta;
@@ -317,7 +320,6 @@ inline mtmc::RoundParams round_params(const Ctx& x, int r) {
   // (few-edge graphs are latency-bound: there the extra statistics gather in two prologues costs more than the bytes save)
   p.lazy_e = lazy_edges(x.c) ? 1 : 0;
   p.prev_stats = r > 0 ? p.stats - mtmc::kRoundBlock : nullptr;
-  p.seg = x.at<double>(x.lo.pub.seg_off);
   p.h_acc = agg_target(x, r);
   const int step = r + 1;
   int first_cls = m->num_enc_steps - m->num_class_steps + 1;   // mpn.py:277; Cs > L classifies every round
@@ -369,6 +371,18 @@ inline int l0_panels(int64_t rows, int Nout, int64_t* cuts, int* bm) {
     if (k < 8) k *= 2;
   }
   return np;
+}
+
+// Few-row graphs: the last node-encoder layer is a handful of workgroups (S02: 8) on the in-loop kernel, and the edge branch's
+// second kernel (enc2: moments of the edge encoder's hidden layer, needed from the first round on) is independent of the whole
+// encoder chain -- it rides in that launch as passenger workgroups (GemmParams::pass_*; -1 launch per forward).
+inline bool enc2_can_ride(const Ctx& x) {
+  const int last = x.m->n_enc_layers - 1;
+  const int64_t rows = x.c->node_hi - x.c->node_lo;
+  if (x.c->n_edges <= 0 || rows <= 0 || x.c->n_edges > (int64_t)2048 * 256) return false;
+  if ((last == 0 && use_presplit0(x)) || use_staged(x, last) || use_rows(x, last)) return false;
+  int sk;
+  return mtmc::gemm_plan(rows, x.m->enc_node[last].in_dim, x.m->enc_node[last].out_dim, &sk) == 1;
 }
 
 enum { kPhMemset = -1, kPhPrep = -2 };   // the two halves of MTMC_PH_BEGIN, for the forked forward
@@ -511,6 +525,12 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
         g.amax_w = x.at<unsigned>(x.lo.amax_w) + arg * mtmc::kAmaxRep;
         g.amax_y = amax + (1 + MTMC_MAX_ENC_LAYERS + arg) * mtmc::kAmaxRep;
       }
+      if (x.enc2_rides && phase == MTMC_PH_NODE_ENC && arg == m->n_enc_layers - 1) {
+        const int64_t blocks = (c->n_edges + 255) / 256;
+        g.pass_blocks = (int)(blocks > 2048 ? 2048 : blocks);
+        g.pass_enc = enc_params(x); g.pass_attr = c->edge_attr; g.pass_edges = c->n_edges;
+        g.pass_e_total = (double)c->n_edges_total; g.pass_stat = x.at<double>(x.lo.pub.stat_enc2_off);
+      }
       if (use_rows(x, arg)) {
         if (phase == MTMC_PH_NODE_COMBINE) break;                // never split along K
         g.slab = nullptr; g.split_k = 1;
@@ -558,6 +578,9 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
       p.zero_buf = agg_target(x, arg);
       p.n_nodes = c->n_nodes;
       p.node_begin = proj_lo(c); p.node_end = proj_hi(c);
+      p.edge_deg = x.at<int>(x.lo.pub.deg_off); p.un_b = m->upd_node.bias;
+      p.z2_stats = mtmc::fold_node_stat(c->n_edges)
+                       ? x.at<double>(x.lo.pub.stat_round_off) + (size_t)arg * mtmc::kRoundBlock + mtmc::kRoundZ2Off : nullptr;
       mtmc::launch_node_proj(p, s);
       break;
     }
@@ -572,8 +595,9 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
       else mtmc::launch_pass_c(p, s);
       break;
     }
-    case MTMC_PH_ROUND_STAT: {
+    case MTMC_PH_ROUND_STAT: {     // few-edge lists: nothing (the statistics came out of MTMC_PH_ROUND_PROJ + MTMC_PH_ROUND_B)
       if (arg < 0 || arg >= L) return fail(MTMC_E_ARG, "round %d out of range", arg);
+      if (mtmc::fold_node_stat(c->n_edges)) break;
       mtmc::NodeStatParams p;
       p.Q = round_Q(x, arg); p.deg = x.at<int>(x.lo.pub.deg_off); p.seg = x.at<double>(x.lo.pub.seg_off);
       p.un_w = m->upd_node.weight; p.un_b = m->upd_node.bias; p.un_ld = m->upd_node.in_dim;

@@ -166,8 +166,9 @@ __device__ __forceinline__ void stat_gather2(const double* srcA, int nA, int str
 // Block-wide sum of NV per-thread doubles; result atomically added to this block's replica of dst.
 // smem: at least NV * (blockDim.x/64) doubles.  All threads must call.
 template <int NV>
-__device__ __forceinline__ void block_atomic_add(const double (&v)[NV], double* dst_base, int stride, double* smem) {
-  double* dst = dst_base + (blockIdx.x % kStatRep) * stride;
+__device__ __forceinline__ void block_atomic_add(const double (&v)[NV], double* dst_base, int stride, double* smem,
+                                                 int block = -1) {   // block: replica chooser (default: blockIdx.x)
+  double* dst = dst_base + ((block < 0 ? (int)blockIdx.x : block) % kStatRep) * stride;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -303,6 +304,33 @@ __device__ __forceinline__ void edge_enc_out(const EdgeEncParams& p, const EdgeE
     for (int j = 0; j < 4; ++j) z = fmaf(p.w2[k * 4 + j], u[j], z);
     e[k] = drop_apply(p.drop, kDropEncEdge2, (unsigned long long)eidx * 4 + k, fmaxf(fmaf(z, af.s2[k], af.t2[k]), 0.f));
   }
+}
+
+__device__ __forceinline__ void load_attr(const float* attr, int fe, int64_t e, float& a0, float& a1);
+
+// Moments of the edge encoder's hidden activations (enc2): workgroup `block` of `n_blocks`, 256 threads.  The body of
+// enc2_kernel (edge_kernels.hip) and of the passenger workgroups the few-row encoder GEMM carries (gemm_bn.hip).
+__device__ __forceinline__ void enc2_body(const EdgeEncParams& enc, const float* attr, int64_t n_edges, double e_total,
+                                          double* stat_enc2, int block, int n_blocks) {
+  __shared__ EdgeEncAffine af;
+  __shared__ double red[14 * 4];
+  edge_enc_affine_to_smem(enc, e_total, 1, &af, red);
+  double acc[14];
+#pragma unroll
+  for (int i = 0; i < 14; ++i) acc[i] = 0;
+  const int64_t nthreads = (int64_t)n_blocks * 256;
+  for (int64_t e = (int64_t)block * 256 + threadIdx.x; e < n_edges; e += nthreads) {
+    float a0, a1, u[4];
+    load_attr(attr, enc.fe, e, a0, a1);
+    edge_enc_hidden(enc, af, e, a0, a1, u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[i] += u[i];
+#pragma unroll
+      for (int j = i; j < 4; ++j) acc[4 + tri(4, i, j)] += (double)u[i] * u[j];
+    }
+  }
+  block_atomic_add<14>(acc, stat_enc2, kEnc2Stride, red, block);
 }
 
 // the same for a stream's last reader (non-temporal: the line is not kept in L2 / Infinity Cache)

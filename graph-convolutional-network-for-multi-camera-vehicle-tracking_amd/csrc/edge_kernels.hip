@@ -108,25 +108,7 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepParams p) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void enc2_kernel(EdgeEncParams enc, const float* attr, int64_t n_edges,
                                                    double e_total, double* stat_enc2) {
-  __shared__ EdgeEncAffine af;
-  __shared__ double red[14 * 4];
-  edge_enc_affine_to_smem(enc, e_total, 1, &af, red);
-  double acc[14];
-#pragma unroll
-  for (int i = 0; i < 14; ++i) acc[i] = 0;
-  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += nthreads) {
-    float a0, a1, u[4];
-    load_attr(attr, enc.fe, e, a0, a1);
-    edge_enc_hidden(enc, af, e, a0, a1, u);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      acc[i] += u[i];
-#pragma unroll
-      for (int j = i; j < 4; ++j) acc[4 + tri(4, i, j)] += (double)u[i] * u[j];
-    }
-  }
-  block_atomic_add<14>(acc, stat_enc2, kEnc2Stride, red);
+  enc2_body(enc, attr, n_edges, e_total, stat_enc2, blockIdx.x, gridDim.x);   // (common.h: also carried by the few-row GEMM)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -536,12 +518,29 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 4 : 1)) void pass_a_blocked_kerne
   block_atomic_add<8>(acc, p.stats + kRoundZ1Off, kZ1Stride, red);
 }
 
-// e' = relu(bn(z1)) in place; second moments of e'; per-node segment sums of e'
+// e' = relu(bn(z1)) in place; first / second moments of e'; and the edge-dependent part of the node-update statistics.
+// z2 = Q[row] + A e' + b (32-wide) is never materialised for its BatchNorm statistics:
+//   sum_e z2_k   = sum_i deg_i qb_ik                          + A_k . m1            qb = Q + b, m1 = sum_e e'
+//   sum_e z2_k^2 = sum_i deg_i qb_ik^2 + 2 A_k . C[:,k]       + A_k M2 A_k^T        C[j][k] = sum_e e'_j qb[row_e][k]
+// The node-only sums come from node_proj (it has Q in registers), M2 is this pass's second moments (the consumers add the
+// quadratic form), and C -- 4 x 32 numbers -- is accumulated here PER RUN of equal rows: a run's four channel sums (the wave
+// sums this pass takes anyway) times the row's qb (one 128-byte line), two fp64 FMAs per lane.  Round 4: this replaces the
+// per-node segment sums (fp64 atomics per run and channel into seg[N][4]) AND node_stat_kernel, the O(N) kernel that turned
+// them into the statistics: one launch less per round, 3 of the 25 of the S02 forward.  Any row order is correct; runs of
+// length one (a randomly ordered list) pay one dependent 128-byte load per edge here -- the reference's lists are cartesian
+// products, runs of hundreds.
 template <int kEPT>
 __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
   __shared__ float s1[4], t1[4];
-  __shared__ double red[14 * 4];
+  __shared__ double red[14 * 4 + 4 * 128 + 4];
   const int lane = threadIdx.x & 63;
+  // few-edge lists (one edge per thread) fold the statistics in as described; many-edge lists keep the per-node segment
+  // sums + node_stat_kernel (kernels.h, fold_node_stat): pass B is issue-bound there and the fold costs it 15 instructions
+  // per 64 edges
+  constexpr bool kFold = kEPT == 1;
+  const int k32 = lane & 31, hh = lane >> 5;             // C entries of this lane: channels (2 hh, 2 hh + 1) x column k32
+  const float ub = p.un_b[k32];
+  double c0 = 0, c1 = 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * kEPT;
   const int64_t e_end = ((p.n_edges + 63) / 64) * 64;
   int64_t base = (int64_t)blockIdx.x * blockDim.x * kEPT + threadIdx.x;
@@ -606,6 +605,26 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
         if (!p.lazy_e) reinterpret_cast<float4*>(p.e_out)[e] = make_float4(vv[i][0], vv[i][1], vv[i][2], vv[i][3]);
       }
     }
+    // qb[row][k32] of every wave-trip's first and last row, requested before the moments are taken: by the time the
+    // run sums exist the 128-byte lines are there (rows of inactive lanes: -1 -> row 0, never used)
+    float qf[kEPT], ql[kEPT];
+#pragma unroll
+    for (int i = 0; i < kEPT; ++i) {
+      qf[i] = ql[i] = 0.f;
+      if (kFold) {
+        const int rf = __builtin_amdgcn_readfirstlane(rr[i]), rl = __builtin_amdgcn_readlane(rr[i], 63);
+        qf[i] = p.Q[(int64_t)(rf < 0 ? 0 : rf) * kH + k32];
+        ql[i] = p.Q[(int64_t)(rl < 0 ? 0 : rl) * kH + k32];
+      }
+    }
+    // (the readlane builtin is typed int: a float argument would be CONVERTED, not moved)
+    auto rl_f32 = [](float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); };
+    // a run's channel sums (S0..S3, wave-uniform) times the row's qb: this lane's two entries of C
+    auto add_run = [&](float S0, float S1, float S2, float S3, float qrow) {
+      const double qb = (double)(qrow + ub);
+      c0 = fma((double)(hh ? S2 : S0), qb, c0);
+      c1 = fma((double)(hh ? S3 : S1), qb, c1);
+    };
 #pragma unroll
     for (int i = 0; i < kEPT; ++i) {
       const int64_t e = base + i * 256;
@@ -619,31 +638,37 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
 #pragma unroll
         for (int b = a; b < 4; ++b) acc[4 + tri(4, a, b)] += (double)v[a] * v[b];
       }
-      // per-node segment sums S[row] += e'.  Common case on row-sorted lists: the whole wave sits in one row ->
-      // one DPP wave sum per channel and 4 atomics.  Otherwise a segmented inclusive scan over the wave (any row
-      // order), then one fp64 atomic per run and channel.
+      // Common case on row-sorted lists: the whole wave sits in one row -> one ten-instruction wave sum for the four
+      // channels (lanes 15 / 31 / 47 / 63 end up with channels 0 / 2 / 1 / 3).
       const int r0 = __builtin_amdgcn_readfirstlane(r);
       const unsigned long long in_first = __ballot(r == r0);
       if (in_first == ~0ull && r0 >= 0) {
-        const float t = wave_sum4_f32(v[0], v[1], v[2], v[3]);      // lanes 15 / 31 / 47 / 63: channels 0 / 2 / 1 / 3
-        if ((lane & 15) == 15) unsafeAtomicAdd(p.seg + (int64_t)r0 * 4 + wave_sum4_slot(lane), (double)t);
+        const float t = wave_sum4_f32(v[0], v[1], v[2], v[3]);
+        if (kFold) add_run(rl_f32(t, 15), rl_f32(t, 47), rl_f32(t, 31), rl_f32(t, 63), qf[i]);
+        else if ((lane & 15) == 15) unsafeAtomicAdd(p.seg + (int64_t)r0 * 4 + wave_sum4_slot(lane), (double)t);
         continue;
       }
       // two rows in a whole wave (the next most common case on row-sorted lists at ~100 edges per row): the first row's
-      // share and the total by the same ten-instruction sums, the second row's share as their difference (e' >= 0: no
-      // cancellation beyond the total's rounding)
+      // share and the total by the same sums, the second row's share as their difference (e' >= 0: no cancellation beyond
+      // the total's rounding)
       const int r1 = __builtin_amdgcn_readlane(r, 63);
       if (r0 >= 0 && r1 >= 0 && (in_first | __ballot(r == r1)) == ~0ull) {
         const bool first = r == r0;
         const float tot = wave_sum4_f32(v[0], v[1], v[2], v[3]);
         const float fst = wave_sum4_f32(first ? v[0] : 0.f, first ? v[1] : 0.f, first ? v[2] : 0.f, first ? v[3] : 0.f);
-        if ((lane & 15) == 15) {
+        if (kFold) {
+          const float f0 = rl_f32(fst, 15), f1 = rl_f32(fst, 47);
+          const float f2 = rl_f32(fst, 31), f3 = rl_f32(fst, 63);
+          add_run(f0, f1, f2, f3, qf[i]);
+          add_run(rl_f32(tot, 15) - f0, rl_f32(tot, 47) - f1, rl_f32(tot, 31) - f2, rl_f32(tot, 63) - f3, ql[i]);
+        } else if ((lane & 15) == 15) {
           const int k = wave_sum4_slot(lane);
           unsafeAtomicAdd(p.seg + (int64_t)r0 * 4 + k, (double)fst);
           unsafeAtomicAdd(p.seg + (int64_t)r1 * 4 + k, (double)(tot - fst));
         }
         continue;
       }
+      // anything else (three or more rows, any order, a partial wave): segmented inclusive scan, then run by run
       const int prev = __shfl_up(r, 1, 64);
       int flag = (lane == 0 || prev != r) ? 1 : 0;
       const int next_head = __shfl_down(flag, 1, 64);
@@ -660,15 +685,64 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
           flag = f_up;
         }
       }
-      if (tail) {
+      if (!kFold) {
+        if (tail) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) unsafeAtomicAdd(p.seg + (int64_t)r * 4 + k, (double)v[k]);
+          for (int k = 0; k < 4; ++k) unsafeAtomicAdd(p.seg + (int64_t)r * 4 + k, (double)v[k]);
+        }
+        continue;
+      }
+      unsigned long long tails = __ballot(tail);          // a run's last lane holds the run's sums
+      while (tails) {
+        const int tl = __builtin_amdgcn_readfirstlane(__ffsll((long long)tails) - 1);
+        tails &= tails - 1;
+        const int rt = __builtin_amdgcn_readlane(r, tl);
+        add_run(rl_f32(v[0], tl), rl_f32(v[1], tl), rl_f32(v[2], tl),
+                rl_f32(v[3], tl), p.Q[(int64_t)rt * kH + k32]);
       }
     }
     base += stride;
     if (base < e_end) fetch(base);
   }
-  block_atomic_add<14>(acc, p.stats + kRoundMOff, kMStride, red);
+  // ---- the block's sums: moments of e' -> the M block; A_k . m1 and 2 A_k . C[:,k] -> the node-update (z2) block
+  {
+    const int wid = threadIdx.x >> 6;
+    double* sm_m = red;                  // [4 waves][14]
+    double* sm_c = red + 14 * 4;         // [4 waves][128]: C[j][k] at j * 32 + k
+    double* sm_m1 = sm_c + 4 * 128;      // [4]
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+      const double sacc = wave_sum(acc[i]);
+      if (lane == kWaveSumLane) sm_m[wid * 14 + i] = sacc;
+    }
+    sm_c[wid * 128 + (2 * hh) * 32 + k32] = c0;
+    sm_c[wid * 128 + (2 * hh + 1) * 32 + k32] = c1;
+    __syncthreads();
+    double* m_dst = p.stats + kRoundMOff + (blockIdx.x % kStatRep) * kMStride;
+    if (threadIdx.x < 14) {
+      const double t = sm_m[threadIdx.x] + sm_m[14 + threadIdx.x] + sm_m[28 + threadIdx.x] + sm_m[42 + threadIdx.x];
+      unsafeAtomicAdd(m_dst + threadIdx.x, t);
+      if (threadIdx.x < 4) sm_m1[threadIdx.x] = t;
+    }
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 128) {   // (a wave of its own: not the one that writes sm_m1)
+      const int i = threadIdx.x - 64;
+      sm_c[i] = sm_c[i] + sm_c[128 + i] + sm_c[256 + i] + sm_c[384 + i];
+    }
+    __syncthreads();
+    if (kFold && threadIdx.x < 32) {
+      const int k = threadIdx.x;
+      const float* a = p.un_w + k * p.un_ld + p.un_eoff;
+      double lin = 0, cross = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        lin += (double)a[j] * sm_m1[j];
+        cross += (double)a[j] * sm_c[j * 32 + k];
+      }
+      double* z_dst = p.stats + kRoundZ2Off + (blockIdx.x % kStatRep) * kZ2Stride;
+      unsafeAtomicAdd(z_dst + k, lin);
+      unsafeAtomicAdd(z_dst + 32 + k, 2.0 * cross);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1552,6 +1626,7 @@ int plan_pass_c(int agg, bool deterministic, bool dropout, int64_t n_edges, int6
   return n_edges >= kn.pass_c_small_min ? 2 : 0;
 }
 int plan_edges_per_thread(int64_t n_edges) { return pick_ept(n_edges); }
+bool fold_node_stat(int64_t n_edges) { return pick_ept(n_edges) == 1; }
 // plan value 1 (many-edge list): pass_c_sorted_kernel, or the any-order matrix-core kernel + the walk behind it
 bool pass_c_sorted_taken(int64_t n_nodes) { return !knobs().pass_c_general && n_nodes < kSortedMaxNodes; }
 

@@ -51,11 +51,12 @@ struct RoundParams {
   Drop drop_e, drop_n; unsigned drop_stream;   // training: dropout of the edge / node update MLPs
   const float* P;            // [2][N][4]: Pr rows, then Pc rows (the gathered half compact)
   const float* Q;            // [N][32]
+  double* seg;               // [N][4] per-node segment sums of e' (many-edge lists only: fold_z2 == 0)
+  int fold_z2;               // 1: pass B adds the edge part of the node-update statistics itself (few-edge lists)
   const float* ue_w; const float* ue_b; const float* ue_g; const float* ue_bt; int ue_ld; int ue_eoff;
   const float* un_w; const float* un_b; const float* un_g; const float* un_bt; int un_ld; int un_eoff;
   const float* cls_w; const float* cls_b; int n_classes;
   double* stats;             // this round's kRoundStride doubles
-  double* seg;               // [N][4]
   float* h_acc;              // [N][32] aggregation target (pre-zeroed)
   float* logits;             // this round's [E][C] output or nullptr
   int64_t n_edges; double e_total;
@@ -91,8 +92,15 @@ struct NodeProjParams {
   float* zero_buf;           // [N][32] cleared for the coming aggregation, or nullptr
   int64_t n_nodes;           // N (global): the Pc half of P starts at P + 4 N
   int64_t node_begin, node_end;   // rows to project: [0, N), or the source rows of a row-complete edge shard
+  // the node-only part of the node-update (z2) statistics, taken while Q is in registers: sum_i deg_i qb_ik and
+  // sum_i deg_i qb_ik^2 with qb = Q + un_b and deg = the out-degree over the call's edges (pass B adds the edge part)
+  const int* edge_deg; const float* un_b; double* z2_stats;   // z2_stats: this round's block at kRoundZ2Off, or nullptr
 };
 
+// Many-edge lists keep round 3's form of the node-update statistics: pass B adds per-node segment sums of e' into seg[N][4]
+// (fp64 atomics per run and channel) and node_stat_kernel turns them, Q and the degrees into the sums -- an O(N) kernel of
+// its own, but 15 vector instructions per 64 edges less in pass B, which is issue-bound at those sizes (same-box A/B at
+// config 4: +0.7 % on the forward with the folded form, -4 % on the 150k-edge S02 graph).
 struct NodeStatParams {
   const float* Q; const int* deg; double* seg;
   const float* un_w; const float* un_b; int un_ld; int un_eoff;
@@ -119,6 +127,11 @@ struct GemmParams {
   const unsigned* amax_a = nullptr;  // of A's source: x itself (no stats_in) or the producing layer's raw Y
   const unsigned* amax_w = nullptr;  // of W
   unsigned* amax_y = nullptr;        // out (atomicMax): of this layer's raw Y
+  // Passenger workgroups (few-row graphs): the edge encoder's hidden-layer moments (enc2) ride in this GEMM's launch -- the
+  // encoder chain and the edge branch are independent until the first round, and a few-row GEMM leaves most CUs idle.
+  // launch_gemm_bn runs the job either way: inside the launch where the chosen kernel carries passengers, else behind it.
+  int pass_blocks = 0; EdgeEncParams pass_enc = {}; const float* pass_attr = nullptr; int64_t pass_edges = 0;
+  double pass_e_total = 0; double* pass_stat = nullptr;
 };
 
 // First encoder layer on pre-split operands (gemm_presplit.hip): fp16 planes [2][rows][K] and one power-of-two
@@ -182,6 +195,9 @@ void launch_classify_e0(const EdgeEncParams& enc, const float* attr, int64_t n_e
 
 void launch_node_proj(const NodeProjParams& p, hipStream_t s);
 void launch_node_stat(const NodeStatParams& p, hipStream_t s);
+// few-edge lists (one edge per thread in passes A / B): the node-update statistics come out of node_proj + pass B, no
+// node_stat_kernel launch and no seg[] (RoundParams::fold_z2, NodeProjParams::z2_stats); many-edge lists: seg[] + node_stat
+bool fold_node_stat(int64_t n_edges);
 // h_dst[i][k] = relu(s_k * Y[i][k] + t_k) for local rows; stats over `count` rows
 void launch_bn_relu_rows(const float* Y, int64_t ldy, int64_t rows, int dim, const double* stats, const float* gamma,
                          const float* beta, double count, float* dst, Drop drop, unsigned drop_stream, int64_t row0,

@@ -3,8 +3,10 @@
 //   node_proj_kernel  Pr|Pc = [h0|h] . We[:, node cols]^T  (4+4 per node),  Q = [h0|h] . Wn[:, node cols]^T (32)
 //                     -- the algebraic form of the reference's x[row], x[col] gathers + cat + Linear
 //                        (reference models/mpn.py:48,68 and :97-98): gather 16 B per edge end instead of 128 B
-//   node_stat_kernel  sum / sum of squares over all E edges of z2 = Q[row] + A.e' + b, from per-node segment
-//                     sums of e' and the degree (no pass over the edges)
+//                     + the node-only part of the node-update (z2) BatchNorm statistics, sum_i deg_i qb_ik and
+//                     sum_i deg_i qb_ik^2, on few-edge lists (pass B adds the edge-dependent part: round 4)
+//   node_stat_kernel  many-edge lists: sum / sum of squares over all E edges of z2 = Q[row] + A.e' + b, from per-node
+//                     segment sums of e' and the degree (no pass over the edges)
 //   bn_relu_rows      h0 = relu(bn(Y_last))
 //   h_final           latent_node_feats output (mean aggregation divides by max(deg,1))
 #include "kernels.h"
@@ -24,6 +26,8 @@ __global__ __launch_bounds__(256) void node_proj_kernel(NodeProjParams p) {
   __shared__ float ys[kH], yt[kH];                 // BatchNorm affine of the encoder's last layer (fused round 0)
   __shared__ EdgeEncAffine enc_af;
   __shared__ double scratch[kStatAttr + kStatEnc2];
+  __shared__ double zred[4][2 * kH];               // node-only part of the z2 statistics per wave: sum deg qb | sum deg qb^2
+  double zs1[4] = {0, 0, 0, 0}, zs2[4] = {0, 0, 0, 0};
   const int hn = p.hn, ldh = hn + 2;
   for (int i = threadIdx.x; i < hn * kProjOut; i += blockDim.x) {
     const int kk = i / kProjOut, j = i % kProjOut;
@@ -81,7 +85,35 @@ __global__ __launch_bounds__(256) void node_proj_kernel(NodeProjParams p) {
       p.P[(part < 4 ? node : p.n_nodes + node) * 4 + (part & 3)] = acc[0];      // [Pr | Pc], see edge_z1
 #pragma unroll
       for (int i = 1; i < 5; ++i) p.Q[node * kH + part + 8 * (i - 1)] = acc[i];
+      if (p.z2_stats) {
+        const double d = (double)p.edge_deg[node];
+#pragma unroll
+        for (int i = 1; i < 5; ++i) {
+          const double qb = (double)(acc[i] + p.un_b[part + 8 * (i - 1)]);
+          zs1[i - 1] += d * qb;
+          zs2[i - 1] += d * qb * qb;
+        }
+      }
     }
+  }
+  if (p.z2_stats) {        // a wave holds 4 node lanes (bits 4, 5 of the lane id) x 16: fold them, then the 4 waves through LDS
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      zs1[i] += __shfl_xor(zs1[i], 16, 64); zs2[i] += __shfl_xor(zs2[i], 16, 64);
+      zs1[i] += __shfl_xor(zs1[i], 32, 64); zs2[i] += __shfl_xor(zs2[i], 32, 64);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) < 16 && kh == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        zred[threadIdx.x >> 6][part + 8 * i] = zs1[i];
+        zred[threadIdx.x >> 6][kH + part + 8 * i] = zs2[i];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * kH)
+      unsafeAtomicAdd(p.z2_stats + (blockIdx.x % kStatRep) * kZ2Stride + threadIdx.x,
+                      zred[0][threadIdx.x] + zred[1][threadIdx.x] + zred[2][threadIdx.x] + zred[3][threadIdx.x]);
   }
   if (p.finalize_enc && blockIdx.x == 0) {         // once per forward: the edge encoder's two BatchNorm affines
     edge_enc_affine_to_smem(p.enc, p.e_total, 2, &enc_af, scratch);
@@ -103,8 +135,11 @@ __global__ __launch_bounds__(256) void node_proj_mfma_kernel(NodeProjParams p) {
   __shared__ float ys[kH], yt[kH];
   __shared__ EdgeEncAffine enc_af;
   __shared__ double scratch[kStatAttr + kStatEnc2];
+  __shared__ double zred[4][2 * kH];               // node-only part of the z2 statistics per wave: sum deg qb | sum deg qb^2
+  double zs1[2] = {0, 0}, zs2[2] = {0, 0};         // columns i16 and 16 + i16, this lane's rows
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int i16 = lane & 15, g = lane >> 4;
+  const float ub0 = p.z2_stats ? p.un_b[i16] : 0.f, ub1 = p.z2_stats ? p.un_b[16 + i16] : 0.f;
   if (p.y_last) {
     if (threadIdx.x < kH)
       bn_affine(p.y_stats[threadIdx.x], p.y_stats[kH + threadIdx.x], p.y_count, p.y_gamma[threadIdx.x],
@@ -191,8 +226,32 @@ __global__ __launch_bounds__(256) void node_proj_mfma_kernel(NodeProjParams p) {
         p.Q[on * kH + i16] = acc[0][r];
         p.Q[on * kH + 16 + i16] = acc[1][r];
         if (i16 < 8) p.P[(i16 < 4 ? on : p.n_nodes + on) * 4 + (i16 & 3)] = acc[2][r];
+        if (p.z2_stats) {
+          const double d = (double)p.edge_deg[on];
+          const double q0 = (double)(acc[0][r] + ub0), q1 = (double)(acc[1][r] + ub1);
+          zs1[0] += d * q0; zs2[0] += d * q0 * q0;
+          zs1[1] += d * q1; zs2[1] += d * q1 * q1;
+        }
       }
     }
+  }
+  if (p.z2_stats) {                                // fold the four row groups of a wave, then the waves through LDS
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      zs1[c] += __shfl_xor(zs1[c], 16, 64); zs2[c] += __shfl_xor(zs2[c], 16, 64);
+      zs1[c] += __shfl_xor(zs1[c], 32, 64); zs2[c] += __shfl_xor(zs2[c], 32, 64);
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        zred[wid][16 * c + i16] = zs1[c];
+        zred[wid][kH + 16 * c + i16] = zs2[c];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * kH)
+      unsafeAtomicAdd(p.z2_stats + (blockIdx.x % kStatRep) * kZ2Stride + threadIdx.x,
+                      zred[0][threadIdx.x] + zred[1][threadIdx.x] + zred[2][threadIdx.x] + zred[3][threadIdx.x]);
   }
   if (p.finalize_enc && blockIdx.x == 0) {         // once per forward: the edge encoder's two BatchNorm affines
     __syncthreads();

@@ -18,8 +18,8 @@ hundred bytes to a few KB each), plus the two real data exchanges:
                      snapped to row boundaries): no exchange of h' at all; each rank projects its own rows and the
                      ranks all-gather the column projections Pc                   [N,4]  f32   (8x fewer bytes),
                      and the final node state once at the end                     [N,32] f32
-The per-node segment sums and degrees need no exchange: the z2 statistics are linear in them, so every rank
-evaluates its share and only the 64 sums travel.
+The degrees need no exchange: the node-update (z2) statistics are linear in every rank's share (node-only part over the
+rows it projects with its local degrees, edge part over its edges), so only the 64 sums travel.
 
 The phases are the single-GPU ones (mtmc_mpn_run_phases); this file decides their order (`step_plan`: the node
 encoder's first layers run beside the edge branch so that their statistics share a message), what is exchanged behind
@@ -201,8 +201,8 @@ class ShardedForward:
                         self._sum(g)
             elif what in ("stat_enc2", "stat_enc_node", "round_z1"):
                 self._sum(be.region(prep, what, idx))
-            elif what == "round_m_z2":                  # ROUND_STAT reads only local sums (segment sums, degrees, Q), so the
-                for t in be.region(prep, "round_m_z2", idx):   # e' moments of ROUND_B travel with its z2 sums: one message
+            elif what == "round_m_z2":                  # pass B's e' moments and the node-update (z2) sums -- node-only part
+                for t in be.region(prep, "round_m_z2", idx):   # from ROUND_PROJ, edge part from ROUND_B -- are adjacent: one message
                     self._sum(t)
             elif what == "h0":
                 h0 = be.region(prep, "h0")

@@ -149,7 +149,8 @@ typedef struct mtmc_ws_layout {
   size_t stat_enc_layer_off[MTMC_MAX_ENC_LAYERS];  /* per encoder layer l: f64[2][out_dim_l] column sum | sumsq    */
   size_t stat_round_off;     /* f64[L][ROUND_BLOCK]: per round the z1, e'-moment and z2 blocks in order   */
   size_t deg_off;            /* i32[N]  out-degree of the LOCAL edges (row histogram)                     */
-  size_t seg_off;            /* f64[N][4] per-node segment sums of e' over the LOCAL edges                */
+  size_t seg_off;            /* f64[N][4] per-node segment sums of e' over the LOCAL edges (many-edge lists; zero bytes
+                                on few-edge lists, whose pass B adds the statistics' edge part itself)            */
   size_t h0_off;             /* f32[N][32] encoded node state (rows node_lo..node_hi written locally)      */
   size_t h_acc_off[2];       /* f32[N][32] x2 aggregation ping-pong: round r aggregates into [r & 1],
                                 except that the last round of a sum/max model aggregates into h_out       */
@@ -167,7 +168,8 @@ enum {                       /* phases in forward order; `arg` = encoder layer o
   MTMC_PH_ROUND_PROJ = 4,    /* arg = round: per-node projections Pr|Pc|Q, clear next h buffer   */
   MTMC_PH_ROUND_A = 5,       /* statistics of the edge-update pre-activation                     */
   MTMC_PH_ROUND_B = 6,       /* e' (stored), its moments and per-node segment sums               */
-  MTMC_PH_ROUND_STAT = 7,    /* statistics of the node-update pre-activation by moments          */
+  MTMC_PH_ROUND_STAT = 7,    /* statistics of the node-update pre-activation by moments (many-edge lists; a no-op on
+                                few-edge lists: complete after MTMC_PH_ROUND_PROJ + MTMC_PH_ROUND_B there)      */
   MTMC_PH_ROUND_C = 8,       /* messages, aggregation into h, classifier logits                  */
   MTMC_PH_END = 9,           /* mean scaling / copy of the final node state to h_out             */
   MTMC_PH_NODE_COMBINE = 10  /* arg = layer, right after MTMC_PH_NODE_ENC: sums the split-K slabs of a few-row
