@@ -31,7 +31,7 @@ ARCH = "resnet101"
 XGMI_LINK_GBS = 153.0          # one xGMI link, one direction (7 per GPU, one to every peer); the run is priced at
 XGMI_EFF = 0.65                # 65 % of it for large messages -- a ring step moves one piece over one link
 SMALL_COLLECTIVE_US = 20.0     # an RCCL all-reduce of a few KB (latency-bound; 15-25 us typical on one node)
-LAUNCH_FLOOR_US = 5.0          # a dependent kernel at its floor (the S02 forward: 25 launches at 4-13 us)
+LAUNCH_FLOOR_US = 5.0          # a dependent kernel at its floor (the S02 forward: 21 launches at 5-11 us)
 
 
 def predict_scaling(world, n=1_000_000, e=100_000_000, L=3, stats_csv=None):

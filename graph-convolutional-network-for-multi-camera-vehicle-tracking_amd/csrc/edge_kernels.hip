@@ -578,8 +578,23 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
       }
     }
   };
+  // qb[row][k32] of every wave-trip's first and last row (folded form): requested as soon as the row ids are there -- for the
+  // first trip that is BEFORE the block waits for the z1 statistics, so the 128-byte lines travel during the prologue
+  float qf[kEPT], ql[kEPT];
+  auto prefetch_q = [&]() {
+#pragma unroll
+    for (int i = 0; i < kEPT; ++i) {
+      qf[i] = ql[i] = 0.f;
+      if (kFold) {
+        const int rf = __builtin_amdgcn_readfirstlane(rr[i]), rl = __builtin_amdgcn_readlane(rr[i], 63);
+        qf[i] = p.Q[(int64_t)(rf < 0 ? 0 : rf) * kH + k32];
+        ql[i] = p.Q[(int64_t)(rl < 0 ? 0 : rl) * kH + k32];
+      }
+    }
+  };
   if (base < e_end) fetch(base);
   stat_gather(p.stats + kRoundZ1Off, 8, kZ1Stride, red);
+  if (base < e_end) prefetch_q();
   __syncthreads();
   if (threadIdx.x < 4) {
     const int k = threadIdx.x;
@@ -589,6 +604,7 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
   double acc[14];
 #pragma unroll
   for (int i = 0; i < 14; ++i) acc[i] = 0;
+  bool first_trip = true;
   while (base < e_end) {
     const bool full = whole(base);
     float vv[kEPT][4];
@@ -605,18 +621,10 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
         if (!p.lazy_e) reinterpret_cast<float4*>(p.e_out)[e] = make_float4(vv[i][0], vv[i][1], vv[i][2], vv[i][3]);
       }
     }
-    // qb[row][k32] of every wave-trip's first and last row, requested before the moments are taken: by the time the
-    // run sums exist the 128-byte lines are there (rows of inactive lanes: -1 -> row 0, never used)
-    float qf[kEPT], ql[kEPT];
-#pragma unroll
-    for (int i = 0; i < kEPT; ++i) {
-      qf[i] = ql[i] = 0.f;
-      if (kFold) {
-        const int rf = __builtin_amdgcn_readfirstlane(rr[i]), rl = __builtin_amdgcn_readlane(rr[i], 63);
-        qf[i] = p.Q[(int64_t)(rf < 0 ? 0 : rf) * kH + k32];
-        ql[i] = p.Q[(int64_t)(rl < 0 ? 0 : rl) * kH + k32];
-      }
-    }
+    // (later trips: requested before the moments are taken -- by the time the run sums exist the lines are there; rows of
+    // inactive lanes: -1 -> row 0, never used)
+    if (!first_trip) prefetch_q();
+    first_trip = false;
     // (the readlane builtin is typed int: a float argument would be CONVERTED, not moved)
     auto rl_f32 = [](float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); };
     // a run's channel sums (S0..S3, wave-uniform) times the row's qb: this lane's two entries of C

@@ -41,9 +41,16 @@ __global__ __launch_bounds__(256) void node_proj_kernel(NodeProjParams p) {
     bn_affine(p.y_stats[threadIdx.x], p.y_stats[kH + threadIdx.x], p.y_count, p.y_gamma[threadIdx.x],
               p.y_beta[threadIdx.x], ys[threadIdx.x], yt[threadIdx.x]);
   const int nl = threadIdx.x >> 4, part = (threadIdx.x >> 1) & 7, kh = threadIdx.x & 1;
+  float ubv[4] = {0.f, 0.f, 0.f, 0.f};             // un_b of this lane's four Q channels (node-only z2 statistics)
+  if (p.z2_stats) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ubv[i] = p.un_b[part + 8 * i];
+  }
   const int64_t n_groups = (p.node_end - p.node_begin + kProjNodes - 1) / kProjNodes;
   for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
     const int64_t node0 = p.node_begin + g * kProjNodes;
+    // (the node's out-degree: requested here, used after the projections)
+    const double dnode = (p.z2_stats && node0 + nl < p.node_end) ? (double)p.edge_deg[node0 + nl] : 0.0;
     __syncthreads();                               // wt/ys ready / previous hs consumed
     // stage the h rows of 32 nodes (1024 floats), then mirror / fetch the h0 half when reattaching
     for (int i = threadIdx.x; i < kProjNodes * kH; i += blockDim.x) {
@@ -86,12 +93,11 @@ __global__ __launch_bounds__(256) void node_proj_kernel(NodeProjParams p) {
 #pragma unroll
       for (int i = 1; i < 5; ++i) p.Q[node * kH + part + 8 * (i - 1)] = acc[i];
       if (p.z2_stats) {
-        const double d = (double)p.edge_deg[node];
 #pragma unroll
         for (int i = 1; i < 5; ++i) {
-          const double qb = (double)(acc[i] + p.un_b[part + 8 * (i - 1)]);
-          zs1[i - 1] += d * qb;
-          zs2[i - 1] += d * qb * qb;
+          const double qb = (double)(acc[i] + ubv[i - 1]);
+          zs1[i - 1] += dnode * qb;
+          zs2[i - 1] += dnode * qb * qb;
         }
       }
     }

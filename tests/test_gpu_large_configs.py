@@ -94,10 +94,29 @@ def test_config5_full_size_against_fp64_oracle_on_device_and_properties():
     print(f"config 5 full size: max |logit - fp64 oracle (device)| = {err:.3e}")
 
 
+def _skewed_graph(N, E, seed):
+    """Row-sorted list with ascending columns whose rows are very unequal: two thirds of the nodes have no out-edge at all
+    (whole 64-row waves of the blocked traversal are empty), a handful have thousands (sub-runs far longer than a wave's trip),
+    columns cluster in the first column block for a tenth of the rows (seven of eight sub-runs empty), duplicates allowed."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    src = torch.randperm(N, device="cuda", generator=g)[:N // 3]
+    w = torch.rand(src.numel(), device="cuda", generator=g)
+    w[:8] = 400.0                                            # eight rows with ~1/6 of all edges each ... well, thousands
+    row = src[torch.multinomial(w, E, replacement=True, generator=g)]
+    col = torch.randint(0, N, (E,), device="cuda", generator=g)
+    narrow = (row % 10) == 0
+    col[narrow] = col[narrow] % (N // 8)
+    key, _ = torch.sort(row * N + col)
+    ei = torch.stack([key // N, key % N])
+    x = torch.randn(N, 2048, device="cuda", generator=g)
+    return types.SimpleNamespace(x=x, edge_index=ei, edge_attr=torch.rand(E, 2, device="cuda", generator=g))
+
+
 @pytest.mark.parametrize("over,unsort_cols", [
     (dict(num_enc_steps=2, num_class_steps=2), False),                                   # first-round + later-round kernels
     (dict(num_enc_steps=2, num_class_steps=1, reattach_initial_edges=True, reattach_initial_nodes=True), False),
     (dict(num_enc_steps=2, num_class_steps=1), True),       # columns shuffled inside the rows: the in-order kernel must take over
+    (dict(num_enc_steps=2, num_class_steps=1), "skewed"),   # empty rows, huge rows, empty sub-runs
 ])
 def test_column_blocked_pass_a_regime(over, unsort_cols):
     """Pass A by column blocks (csrc/edge_kernels.hip pass_a_blocked_kernel: graphs whose Pc table, 16 B per node, outgrows
@@ -110,10 +129,10 @@ def test_column_blocked_pass_a_regime(over, unsort_cols):
     m = mtmc_mpn.MOTMPNet(copy.deepcopy(params), None, ARCH).eval()
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     N, E = 230_000, 9_200_000
-    d = graphs.stress_graph(N, E // 2, seed=11, device="cuda")
+    d = _skewed_graph(N, E, 12) if unsort_cols == "skewed" else graphs.stress_graph(N, E // 2, seed=11, device="cuda")
     plan = engine.ForwardEngine(m).plan(N, E)
     assert plan.pass_a_col_blocks == 8 and plan.pass_c == _lib.PASS_C_MFMA_SORTED
-    if unsort_cols:                                          # same rows, columns of each row in random order
+    if unsort_cols is True:                                  # same rows, columns of each row in random order
         perm = torch.argsort(d.edge_index[0] * 4 + torch.randint(0, 4, (E,), device="cuda"), stable=True)
         d.edge_index, d.edge_attr = d.edge_index[:, perm].contiguous(), d.edge_attr[perm].contiguous()
         assert (d.edge_index[0][1:] >= d.edge_index[0][:-1]).all()

@@ -208,6 +208,32 @@ def test_many_row_encoder_with_ragged_tile_heights(n):
     _check(got, h, want64, h64, f"N={n}")
 
 
+def test_pipelined_layer0_panels_eager_and_captured():
+    """Layer 0 of a many-row graph runs in row panels, the operand split of panel i + 1 on a side stream beside panel i's GEMM
+    (api_internal.h l0_panels; round 4).  30 000 rows = two panels with a ragged second one (the full-size configs take 3 and
+    10): against the fp64 oracle, and the same forward recorded into a HIP graph (the side stream's work joins the capture
+    through the events) must replay to the same numbers, also after the inputs changed."""
+    m, sd, params = _model(1, 1)
+    n = 30_000
+    d = _random_sorted_graph(n, 60_000, seed=5)
+    m = m.cuda()
+    got, h = _gpu(m, d, transposed_view=False)
+    want64, h64 = _oracle(sd, params, d)
+    _check(got, h, want64, h64, "pipelined layer 0, eager")
+    data = types.SimpleNamespace(x=d.x.cuda(), edge_index=d.edge_index.cuda(), edge_attr=d.edge_attr.cuda())
+    with torch.no_grad():
+        replay = m.capture(data)
+        out, h2 = replay()
+        torch.cuda.synchronize()
+        assert (out["classified_edges"][0].cpu() - got[0]).abs().max().item() <= 2e-6
+        data.x.mul_(1.5)                                  # new values in the captured input tensor
+        want, want_h = m(types.SimpleNamespace(x=data.x.clone(), edge_index=data.edge_index, edge_attr=data.edge_attr))
+        want = want["classified_edges"][0].clone()
+        out, h2 = replay()
+        torch.cuda.synchronize()
+        assert (out["classified_edges"][0] - want).abs().max().item() <= 2e-6
+
+
 @pytest.mark.parametrize("over", [dict(reattach_initial_nodes=True), dict(reattach_initial_nodes=True, reattach_initial_edges=True),
                                   dict(node_agg_fn="mean"), dict(node_agg_fn="max")],
                          ids=["reattach_nodes", "reattach_both", "mean", "max"])
