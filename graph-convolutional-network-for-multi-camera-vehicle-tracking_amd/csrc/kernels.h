@@ -163,6 +163,7 @@ struct StagedGemmParams {
 };
 bool staged_layer(int64_t rows, int K, int Nout);       // many rows, K % 32 == 0, K <= 2048, Nout % 256 == 0 or (Nout == 128, rows >= 49152), not disabled
 int launch_gemm_staged(const StagedGemmParams& p, hipStream_t s);   // 0 ok, 1 unsupported shape, MTMC_E_HIP
+int staged_tile_rows(int64_t M, int tiles_n, int wm);   // (also used by the laboratory's second form, lab/staged2_lab.hip)
 // The last, narrow encoder layers of many-row graphs as a row-streaming kernel (gemm_rows.hip): 128 -> 32
 bool rows_layer(int64_t rows, int K, int Nout);
 int launch_gemm_rows(const GemmParams& p, hipStream_t s);          // 0 ok, 1 unsupported shape

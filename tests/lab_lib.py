@@ -1,5 +1,5 @@
-"""Loader of the kernel laboratory (csrc/lab/ -> libmtmc_lab.so): A/B variants and timing experiments of the pre-split GEMM,
-some with deliberately wrong results.  Test / tool infrastructure: used by tests/test_gpu_gemm_presplit.py,
+"""Loader of the kernel laboratory (csrc/lab/ -> libmtmc_lab.so): A/B variants and timing experiments of the pre-split GEMM
+(some with deliberately wrong results) and the second form of the role-split GEMM (lab/staged2_lab.hip).  Test / tool infrastructure: used by tests/test_gpu_gemm_presplit.py,
 tools/presplit_time.py and tools/gemm_clock_watch.py -- the product package has no reference to it."""
 import ctypes as C
 import os
@@ -21,4 +21,8 @@ def load_lab() -> C.CDLL:
         _lab.mtmc_lab_linear_presplit_raw.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                                       C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                                       C.c_int32, C.c_void_p]
+        _lab.mtmc_lab_linear_staged2_raw.restype = C.c_int32
+        _lab.mtmc_lab_linear_staged2_raw.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                                     C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
     return _lab

@@ -9,7 +9,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(A, gamma, beta, W, b, count=None):
+def _run(A, gamma, beta, W, b, count=None, lab=False):
+    """lab=True: the kernel laboratory's second form of the role-split kernel (csrc/lab/staged2_lab.hip, libmtmc_lab.so:
+    W fragments straight into registers, four A stages, one barrier per two k-tiles) through the same argument list."""
     from mtmc_mpn import _lib
     lib = _lib.load()
     M, K = A.shape
@@ -20,9 +22,14 @@ def _run(A, gamma, beta, W, b, count=None):
     work = torch.empty(4 * N * K + 4 * N + 512, dtype=torch.uint8, device="cuda")
     scr = torch.zeros(48, dtype=torch.int32, device="cuda")
     st = torch.empty(2 * N, dtype=torch.float64, device="cuda")
-    _lib.check(lib.mtmc_linear_staged_raw(A.data_ptr(), A.stride(0), st_in.data_ptr(), gamma.data_ptr(), beta.data_ptr(), count,
-                                          W.data_ptr(), b.data_ptr(), Y.data_ptr(), M, K, N, work.data_ptr(), work.numel(),
-                                          scr.data_ptr(), st.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    args = (A.data_ptr(), A.stride(0), st_in.data_ptr(), gamma.data_ptr(), beta.data_ptr(), count,
+            W.data_ptr(), b.data_ptr(), Y.data_ptr(), M, K, N, work.data_ptr(), work.numel(),
+            scr.data_ptr(), st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    if lab:
+        import lab_lib
+        assert lab_lib.load_lab().mtmc_lab_linear_staged2_raw(*args) == 0
+    else:
+        _lib.check(lib.mtmc_linear_staged_raw(*args))
     torch.cuda.synchronize()
     return Y, st, scr[32:48].view(torch.float32).max().item(), st_in
 
@@ -67,6 +74,28 @@ def test_staged_matches_float64(shape):
     assert (a[:, 0] == 0).all()
     err = ((Y.double() - ref).abs() / bound).max().item()
     assert err < 1.0, err
+    assert ymax == Y.abs().max().item()
+    assert torch.allclose(st[:N], Y.double().sum(0), rtol=1e-9, atol=1e-9 * Y.abs().max().item() * M)
+    assert torch.allclose(st[N:], (Y.double() ** 2).sum(0), rtol=1e-9)
+
+
+@pytest.mark.parametrize("shape", [(128, 128, 256), (1000, 512, 768), (777, 1024, 512), (4100, 2048, 256), (20011, 192, 512)])
+def test_laboratory_second_form_matches_float64(shape):
+    """The laboratory's second form of the role-split kernel (measured equal to the product's: profiles/r04_staged2_ab.txt):
+    same bound as the product kernel, ragged tile heights, odd counts of two-k-tile intervals (K = 192: three)."""
+    M, K, N = shape
+    g = torch.Generator(device="cuda").manual_seed(M + 5 * N)
+    A = torch.randn(M, K, device="cuda", generator=g) * (1 + 4 * torch.rand(1, K, device="cuda", generator=g)) + \
+        torch.randn(1, K, device="cuda", generator=g)
+    gamma = 0.5 + torch.rand(K, device="cuda", generator=g)
+    beta = 0.2 * torch.randn(K, device="cuda", generator=g)
+    beta[0] = -50.0
+    W = (torch.rand(N, K, device="cuda", generator=g) * 2 - 1) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    Y, st, ymax, st_in = _run(A, gamma, beta, W, b, lab=True)
+    a, ref, bound = _ref(A, st_in, gamma, beta, W, b, float(M), split=2.0 ** -19 if K < 512 else 5e-7)
+    assert torch.isfinite(Y).all()
+    assert ((Y.double() - ref).abs() / bound).max().item() < 1.0
     assert ymax == Y.abs().max().item()
     assert torch.allclose(st[:N], Y.double().sum(0), rtol=1e-9, atol=1e-9 * Y.abs().max().item() * M)
     assert torch.allclose(st[N:], (Y.double() ** 2).sum(0), rtol=1e-9)

@@ -23,9 +23,16 @@ scr = torch.zeros(48, dtype=torch.int32, device="cuda")
 st = torch.empty(2 * N, dtype=torch.float64, device="cuda")
 
 
+fn = lib.mtmc_linear_staged_raw
+if os.environ.get("STAGED_LAB", "0") not in ("", "0"):       # the kernel laboratory's second form (csrc/lab/staged2_lab.hip)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import lab_lib  # noqa: E402
+    fn = lab_lib.load_lab().mtmc_lab_linear_staged2_raw
+
+
 def run():
-    rc = lib.mtmc_linear_staged_raw(A.data_ptr(), K, st_in.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(M), W.data_ptr(),
-                                    b.data_ptr(), Y.data_ptr(), M, K, N, work.data_ptr(), work.numel(), scr.data_ptr(), st.data_ptr(), s)
+    rc = fn(A.data_ptr(), K, st_in.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(M), W.data_ptr(),
+            b.data_ptr(), Y.data_ptr(), M, K, N, work.data_ptr(), work.numel(), scr.data_ptr(), st.data_ptr(), s)
     assert rc == 0, lib.mtmc_mpn_last_error()
 
 
