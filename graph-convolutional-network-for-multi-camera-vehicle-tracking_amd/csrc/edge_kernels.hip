@@ -384,7 +384,13 @@ __global__ __launch_bounds__(256) void colblock_index_kernel(const int* __restri
           const int mid = (lo + hi) >> 1;
           if (col32[mid] < want) lo = mid + 1; else hi = mid;
         }
-        pos = lo;
+        // Inner boundaries snap DOWN to a multiple of four edges = one 64-byte sector of the 16-byte-per-edge streams (z1 in and
+        // out): a sector is then read and written by ONE column block, i.e. one XCD -- unsnapped, the first and last sector of
+        // every ~200-byte sub-run were shared with the neighbouring block on another XCD, fetched twice and written in two
+        // partial pieces.  The <= 3 edges this moves into the neighbour's block gather from the neighbour's slice of Pc (a miss
+        // in this XCD's L2, nothing else); monotone boundaries stay monotone under rounding.
+        pos = lo & ~3;
+        pos = pos < s0 ? s0 : pos;
       }
     }
     sub[(r - row_lo) * (B + 1) + b] = pos;                   // (a row without edges: all zeros -> empty sub-runs)
