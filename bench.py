@@ -381,7 +381,8 @@ def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
            "phase_ms_sum": sum(ms), "phase_ms": {k: round(v, 4) for k, v in phases.items()},
            "plan": {"encoder_kernels": enc_names, "enc_split_k": plan.enc_split_k, "edges_per_thread": plan.edges_per_thread,
                     "lazy_edges": plan.lazy_edges, "pass_c": ["walk", "mfma_sorted", "mfma_any"][plan.pass_c],
-                    "pass_a_col_blocks": plan.pass_a_col_blocks,
+                    "pass_a_col_blocks": plan.pass_a_col_blocks, "layer0_panels": plan.layer0_panels,
+                    "enc2_passenger": plan.enc2_passenger, "node_stat_folded": plan.node_stat_folded,
                     "layer0_pipeline": os.environ.get("MTMC_L0_PIPELINE", "1 (default: row panels, split on a side stream)")}}
     if with_cpu:
         sd = {k: v.detach().clone() for k, v in model.state_dict().items()}

@@ -64,7 +64,8 @@ class Plan(C.Structure):
     """mtmc_mpn_plan: which kernels a call would run (host-only query)."""
     _fields_ = [("enc_kernel", C.c_int32 * MAX_ENC_LAYERS), ("enc_split_k", C.c_int32 * MAX_ENC_LAYERS),
                 ("edges_per_thread", C.c_int32), ("lazy_edges", C.c_int32), ("pass_c", C.c_int32),
-                ("avg_degree", C.c_double), ("pass_a_col_blocks", C.c_int32)]
+                ("avg_degree", C.c_double), ("pass_a_col_blocks", C.c_int32), ("layer0_panels", C.c_int32),
+                ("enc2_passenger", C.c_int32), ("node_stat_folded", C.c_int32)]
 
 
 GEMM_GENERIC, GEMM_INLOOP_64, GEMM_INLOOP_128, GEMM_PRESPLIT_256, GEMM_STAGED_128, GEMM_ROWS_16 = range(6)

@@ -127,6 +127,23 @@ int32_t mtmc_mpn_plan_call(const mtmc_mpn_model* model, const mtmc_mpn_call* cal
   // (on a many-edge list it still has the walk launched behind it for unsorted rows)
   const int pc = mtmc::plan_pass_c(model->agg, (c->flags & MTMC_F_DETERMINISTIC) != 0, drop_n, c->n_edges, c->n_nodes, out->avg_degree);
   out->pass_c = pc == 1 ? (mtmc::pass_c_sorted_taken(c->n_nodes) ? MTMC_PASS_C_MFMA_SORTED : MTMC_PASS_C_MFMA_ANY) : pc;
+  out->node_stat_folded = mtmc::fold_node_stat(c->n_edges) ? 1 : 0;
+  out->layer0_panels = 1;
+  if (pre0 && mtmc::knobs().l0_pipeline > 0) {
+    int64_t cuts[kMaxPanels + 1];
+    int bm;
+    out->layer0_panels = l0_panels(rows, model->enc_node[0].out_dim, cuts, &bm);
+  }
+  {   // (enc2_can_ride without a Ctx: the same conditions on sizes alone)
+    const int last = model->n_enc_layers - 1;
+    const mtmc_layer& L = model->enc_node[last];
+    int sk;
+    const bool big_last = (last == 0 && pre0) ||
+                          (last >= 1 && !c->training && ((mtmc::staged_layer(c->n_nodes, L.in_dim, L.out_dim) && mtmc::staged_layer(rows, L.in_dim, L.out_dim)) ||
+                                                         (mtmc::rows_layer(c->n_nodes, L.in_dim, L.out_dim) && mtmc::rows_layer(rows, L.in_dim, L.out_dim))));
+    out->enc2_passenger = (c->n_edges > 0 && rows > 0 && c->n_edges <= (int64_t)2048 * 256 && !big_last &&
+                           mtmc::gemm_plan(rows, L.in_dim, L.out_dim, &sk) == 1 && !(c->flags & MTMC_F_FORK)) ? 1 : 0;
+  }
   return MTMC_OK;
 }
 

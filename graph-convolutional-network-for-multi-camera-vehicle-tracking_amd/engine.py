@@ -292,7 +292,9 @@ class ForwardEngine:
         n_layers = len(self.spec.enc_node)
         return types.SimpleNamespace(enc_kernel=list(out.enc_kernel)[:n_layers], enc_split_k=list(out.enc_split_k)[:n_layers],
                                      edges_per_thread=out.edges_per_thread, lazy_edges=bool(out.lazy_edges),
-                                     pass_c=out.pass_c, avg_degree=out.avg_degree, pass_a_col_blocks=out.pass_a_col_blocks)
+                                     pass_c=out.pass_c, avg_degree=out.avg_degree, pass_a_col_blocks=out.pass_a_col_blocks,
+                                     layer0_panels=out.layer0_panels, enc2_passenger=bool(out.enc2_passenger),
+                                     node_stat_folded=bool(out.node_stat_folded))
 
     def phase_list(self):
         """(phase, arg) pairs of one forward, in order (what mtmc_mpn_forward runs internally)."""

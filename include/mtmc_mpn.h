@@ -234,6 +234,13 @@ typedef struct mtmc_mpn_plan {
                                                 gathered projections Pc of a block stay in an XCD's L2 (graphs whose 16 B / node
                                                 table outgrows it; row-sorted lists with ascending columns -- decided on the
                                                 device, the in-order kernel is launched behind it)                     */
+  int32_t layer0_panels;                     /* mtmc_mpn_forward only: row panels of the pre-split layer 0 (the operand split of
+                                                panel i + 1 runs on a side stream beside panel i's GEMM); 1 = one split pass, one
+                                                GEMM (also what mtmc_mpn_run_phase(s) does)                              */
+  int32_t enc2_passenger;                    /* mtmc_mpn_forward only: 1 = MTMC_PH_EDGE_ENC's work rides as passenger workgroups
+                                                in the last node-encoder layer's launch (few-row, few-edge graphs)       */
+  int32_t node_stat_folded;                  /* 1 = few-edge list: the node-update statistics come out of MTMC_PH_ROUND_PROJ +
+                                                MTMC_PH_ROUND_B, MTMC_PH_ROUND_STAT launches nothing                     */
 } mtmc_mpn_plan;
 int32_t mtmc_mpn_plan_call(const mtmc_mpn_model* model, const mtmc_mpn_call* call, mtmc_mpn_plan* out);
 

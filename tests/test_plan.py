@@ -63,6 +63,11 @@ def test_single_gpu_regimes(eng):
     cfg4 = eng.plan(100_000, 10_000_000)
     assert cfg4.enc_kernel[0] == _lib.GEMM_PRESPLIT_256 and cfg4.pass_c == _lib.PASS_C_MFMA_SORTED
     assert cfg4.pass_a_col_blocks == 0 and s02.pass_a_col_blocks == 0      # 1.6 MB of Pc fit an XCD's L2: edge order
+    # round 4: the headline graph's 21 launches -- enc2 rides in the last encoder layer's launch, no node_stat launches -- and
+    # the many-row graphs' pipelined layer 0 (3 panels of 1, 2, 4 rounds at config 4; 10 at config 5)
+    assert s02.enc2_passenger and s02.node_stat_folded and s02.layer0_panels == 1
+    assert not cfg4.enc2_passenger and not cfg4.node_stat_folded and cfg4.layer0_panels == 3
+    assert eng.plan(1_000_000, 100_000_000).layer0_panels == 10 and not trk.node_stat_folded and trk.enc2_passenger is False
     assert eng.plan(1_000_000, 20_000_000).pass_a_col_blocks == 0          # 20 edges per row: sub-runs too short for 8 blocks
     assert eng.plan(1_000_000, 100_000_000, training=True).pass_a_col_blocks == 0
     det = eng.plan(100_000, 10_000_000, flags=_lib.F_DETERMINISTIC)
