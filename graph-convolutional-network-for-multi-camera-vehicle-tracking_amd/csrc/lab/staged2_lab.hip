@@ -39,7 +39,10 @@ constexpr int kS2BM = 128, kS2BN = 256;               // rows of an A stage / co
 constexpr int kS2Stages = 4;                          // A stages: two being read, two being written
 constexpr int kS2AIMG = kS2BM * kS2RowB;              // one piece of one A stage (8 KB)
 constexpr int kS2AST = 2 * kS2AIMG;                   // one A stage (16 KB)
-constexpr int kS2Sets = 4;                            // producer register sets: A is loaded up to three k-tiles ahead
+#ifndef S2_DEEP
+#define S2_DEEP 0                                     // 1: six producer register sets, A requested two intervals (four k-tiles) ahead
+#endif
+constexpr int kS2Sets = S2_DEEP ? 6 : 4;              // producer register sets: A is loaded up to three (five) k-tiles ahead
 
 __global__ __launch_bounds__(kS2NT) void gemm_staged_w_kernel(StagedGemmParams p, int tiles_m, int tiles_n, int bm) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -152,6 +155,34 @@ __global__ __launch_bounds__(kS2NT) void gemm_staged_w_kernel(StagedGemmParams p
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     };
+#if S2_DEEP
+    // six sets, tile k in set k % 6: interval t converts tiles 2t+2, 2t+3 and requests tiles 2t+6, 2t+7 (into the sets of
+    // tiles 2t, 2t+1): every load has two intervals to arrive
+    auto interval6 = [&](int t, int s_cv0, int s_cv1, int s_ld0, int s_ld1) {
+      const int kt = 2 * t;
+      if (kt + 6 < nk) load_a(kt + 6, s_ld0);
+      if (kt + 7 < nk) load_a(kt + 7, s_ld1);
+      if (kt + 2 < nk) convert_a(kt + 2, s_cv0);
+      if (kt + 3 < nk) convert_a(kt + 3, s_cv1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    };
+    load_a(0, 0);
+    load_a(1, 1);
+    if (nk > 2) load_a(2, 2);
+    if (nk > 3) load_a(3, 3);
+    if (nk > 4) load_a(4, 4);
+    if (nk > 5) load_a(5, 5);
+    convert_a(0, 0);
+    convert_a(1, 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // pipeline filled
+    for (int t = 0; t < n_iv; t += 3) {
+      interval6(t, 2, 3, 0, 1);
+      if (t + 1 < n_iv) interval6(t + 1, 4, 5, 2, 3);
+      if (t + 2 < n_iv) interval6(t + 2, 0, 1, 4, 5);
+    }
+#else
     load_a(0, 0);
     load_a(1, 1);
     if (nk > 2) load_a(2, 2);
@@ -164,6 +195,7 @@ __global__ __launch_bounds__(kS2NT) void gemm_staged_w_kernel(StagedGemmParams p
       interval(t, 2, 3, 0, 1);                           // even interval: converts tiles 4u+2, 4u+3, loads into sets 0, 1
       if (t + 1 < n_iv) interval(t + 1, 0, 1, 2, 3);     // odd interval: converts tiles 4u+4, 4u+5 (sets 0, 1), loads into 2, 3
     }
+#endif
   } else {
     // ==== CONSUMERS (waves 4-11, two per SIMD beside one producer): 1 x 8, wave cw owns columns n0 + 32 cw .. + 31 and all
     // rows.  W fragments: global -> registers, one k-tile ahead; A fragments: LDS, two blocks ahead.

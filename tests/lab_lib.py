@@ -6,7 +6,7 @@ import os
 
 from mtmc_mpn import _lib
 
-LAB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libmtmc_lab.so")
+LAB_PATH = os.environ.get("MTMC_LAB_LIB") or os.path.join(os.path.dirname(_lib.LIB_PATH), "libmtmc_lab.so")   # (variant builds: A/B)
 _lab = None
 
 
