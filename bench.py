@@ -116,7 +116,8 @@ def pmc_traffic(workload, kernel, launches_per_step=None):
 
 GEMM_KERNEL_NAMES = {_lib.GEMM_GENERIC: "linear_generic_kernel", _lib.GEMM_INLOOP_64: "gemm_bn_f16x3_kernel",
                      _lib.GEMM_INLOOP_128: "gemm_bn_f16x3_kernel", _lib.GEMM_PRESPLIT_256: "gemm_f16p_m16_kernel",
-                     _lib.GEMM_STAGED_128: "gemm_staged_kernel", _lib.GEMM_ROWS_16: "gemm_rows_kernel"}
+                     _lib.GEMM_STAGED_128: "gemm_staged_kernel", _lib.GEMM_ROWS_16: "gemm_rows_kernel",
+                     _lib.GEMM_FEW_L0: "few_l0_kernel", _lib.GEMM_FEW_WAVE: "few_wave_kernel"}
 
 
 def encoder_kernels(model, n, e):
@@ -344,7 +345,8 @@ def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
     bound = kinds[0][0]
     work = sum(w for _, w in kinds) / len(kinds)
     peak_note = None
-    if bound == "mfma" and dom_key in ("gemm_bn_f16x3_kernel", "gemm_f16p_m16_kernel", "gemm_staged_kernel", "gemm_rows_kernel"):
+    if bound == "mfma" and dom_key in ("gemm_bn_f16x3_kernel", "gemm_f16p_m16_kernel", "gemm_staged_kernel", "gemm_rows_kernel",
+                                       "few_l0_kernel", "few_wave_kernel"):
         achieved, peak, unit = work / (avg_ms * 1e-3) / 1e12, MFMA_BF16_PEAK_TFLOPS / 3.0, "TFLOP/s"
         peak_note = ("algorithmic fp32 flops (2*M*N*K) against the fp16 dense MFMA peak (= the bf16 one) / 3: the kernel "
                      "reaches fp32 accuracy with three fp16 products per fp32 product")

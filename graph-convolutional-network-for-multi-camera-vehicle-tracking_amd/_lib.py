@@ -26,7 +26,7 @@ class Layer(C.Structure):
 
 
 class Model(C.Structure):
-    """mtmc_mpn_model.  struct_bytes (ABI v5) is filled in on construction: the library refuses any other size."""
+    """mtmc_mpn_model.  struct_bytes (since ABI v5) is filled in on construction: the library refuses any other size."""
     _fields_ = [("struct_bytes", C.c_uint32), ("n_enc_layers", C.c_int32), ("enc_node", Layer * MAX_ENC_LAYERS), ("enc_edge", Layer * 2),
                 ("upd_edge", Layer), ("upd_node", Layer), ("cls", Layer),
                 ("agg", C.c_int32), ("num_enc_steps", C.c_int32), ("num_class_steps", C.c_int32),
@@ -45,7 +45,8 @@ class Call(C.Structure):
                 ("n_edges_total", C.c_int64), ("node_lo", C.c_int64), ("node_hi", C.c_int64),
                 ("logits", C.c_void_p), ("h_out", C.c_void_p), ("workspace", C.c_void_p),
                 ("workspace_bytes", C.c_size_t), ("training", C.c_int32), ("flags", C.c_int32),
-                ("seed", C.c_uint64), ("stream", C.c_void_p), ("row_lo", C.c_int64), ("row_hi", C.c_int64)]
+                ("seed", C.c_uint64), ("stream", C.c_void_p), ("row_lo", C.c_int64), ("row_hi", C.c_int64),
+                ("weight_cache", C.c_void_p), ("weight_cache_bytes", C.c_size_t)]
 
     def __init__(self, *args, **kw):
         super().__init__(*args, **kw)
@@ -68,13 +69,14 @@ class Plan(C.Structure):
                 ("enc2_passenger", C.c_int32), ("node_stat_folded", C.c_int32)]
 
 
-GEMM_GENERIC, GEMM_INLOOP_64, GEMM_INLOOP_128, GEMM_PRESPLIT_256, GEMM_STAGED_128, GEMM_ROWS_16 = range(6)
+(GEMM_GENERIC, GEMM_INLOOP_64, GEMM_INLOOP_128, GEMM_PRESPLIT_256, GEMM_STAGED_128, GEMM_ROWS_16, GEMM_FEW_L0,
+ GEMM_FEW_WAVE) = range(8)
 PASS_C_WALK, PASS_C_MFMA_SORTED, PASS_C_MFMA_ANY = range(3)
 
 # statistics blocks (include/mtmc_mpn.h): replicas x stride doubles each
 STAT_REPLICAS, ATTR_STRIDE, ENC2_STRIDE, Z1_STRIDE, M_STRIDE, Z2_STRIDE = 16, 16, 16, 16, 16, 64
 ROUND_BLOCK = STAT_REPLICAS * (Z1_STRIDE + M_STRIDE + Z2_STRIDE)
-F_DETERMINISTIC, F_GLOBAL_DEG, F_FORK, F_WEIGHTS_CACHED = 1, 4, 2, 8
+F_DETERMINISTIC, F_GLOBAL_DEG, F_FORK = 1, 4, 2
 
 # MTMC_MPN_LIB: another build of the same ABI (same-box A/B of two library versions, tools/lib_ab.sh); default: the in-tree build
 LIB_PATH = os.environ.get("MTMC_MPN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmtmc_mpn.so")
@@ -84,7 +86,7 @@ EXPORTS = ["mtmc_mpn_abi_version", "mtmc_mpn_last_error", "mtmc_mpn_workspace_by
            "mtmc_build_graph", "mtmc_postprocess_workspace_bytes", "mtmc_postprocess",
            "mtmc_cross_entropy_forward", "mtmc_cross_entropy_backward",
            "mtmc_cross_entropy_steps_forward", "mtmc_cross_entropy_steps_backward", "mtmc_mpn_backward_steps", "mtmc_mpn_backward_flat", "mtmc_mpn_grad_layout", "mtmc_linear_raw", "mtmc_edge_confusion",
-           "mtmc_linear_presplit_raw", "mtmc_linear_staged_raw"]
+           "mtmc_linear_presplit_raw", "mtmc_linear_staged_raw", "mtmc_linear_few_raw", "mtmc_mpn_weight_cache_bytes"]
 
 _lib = None
 
@@ -103,6 +105,12 @@ def load() -> C.CDLL:
     lib.mtmc_mpn_last_error.restype = C.c_char_p
     lib.mtmc_mpn_workspace_bytes.restype = C.c_size_t
     lib.mtmc_mpn_workspace_bytes.argtypes = [C.POINTER(Model), C.c_int64, C.c_int64]
+    lib.mtmc_mpn_weight_cache_bytes.restype = C.c_size_t
+    lib.mtmc_mpn_weight_cache_bytes.argtypes = [C.POINTER(Model)]
+    lib.mtmc_linear_few_raw.restype = C.c_int32
+    lib.mtmc_linear_few_raw.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64,
+                                        C.c_void_p, C.c_void_p]
     lib.mtmc_mpn_workspace_layout.restype = C.c_int32
     lib.mtmc_mpn_workspace_layout.argtypes = [C.POINTER(Model), C.c_int64, C.c_int64, C.POINTER(WsLayout)]
     lib.mtmc_mpn_forward.restype = C.c_int32
@@ -173,7 +181,7 @@ def load() -> C.CDLL:
     lib.mtmc_mlp_layer_forward.restype = C.c_int32
     lib.mtmc_mlp_layer_forward.argtypes = [C.POINTER(Layer), C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                            C.c_void_p]
-    if lib.mtmc_mpn_abi_version() != 5:
+    if lib.mtmc_mpn_abi_version() != 6:
         raise RuntimeError("mtmc_mpn: ABI version mismatch between _lib.py and libmtmc_mpn.so")
     _lib = lib
     return lib

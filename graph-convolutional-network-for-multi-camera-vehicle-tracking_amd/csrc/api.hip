@@ -69,6 +69,13 @@ size_t mtmc_mpn_workspace_bytes(const mtmc_mpn_model* model, int64_t n_nodes, in
   return lo.pub.total_bytes;
 }
 
+size_t mtmc_mpn_weight_cache_bytes(const mtmc_mpn_model* model) {
+  if (check_model(model) != MTMC_OK) return 0;
+  CacheLayout cl;
+  make_cache_layout(model, &cl);
+  return cl.total > 0 ? cl.total : 256;
+}
+
 int32_t mtmc_mpn_workspace_layout(const mtmc_mpn_model* model, int64_t n_nodes, int64_t n_edges, mtmc_ws_layout* out) {
   if (int rc = check_model(model)) return rc;
   if (!out || n_nodes < 0 || n_edges < 0) return fail(MTMC_E_ARG, "bad layout arguments");
@@ -105,8 +112,17 @@ int32_t mtmc_mpn_plan_call(const mtmc_mpn_model* model, const mtmc_mpn_call* cal
   const int64_t rows = c->node_hi - c->node_lo;
   const bool pre0 = !c->training && mtmc::presplit_layer0(c->n_nodes, model->enc_node[0].in_dim, model->enc_node[0].out_dim) &&
                     mtmc::presplit_layer0(rows, model->enc_node[0].in_dim, model->enc_node[0].out_dim);
+  CacheLayout cl;
+  make_cache_layout(model, &cl);
+  bool few = !c->training && c->weight_cache != nullptr && few_shape(model, c->n_nodes) && few_shape(model, rows);   // use_few
+  for (int l = 0; l < model->n_enc_layers; ++l) few = few && cl.has[l];
   for (int l = 0; l < model->n_enc_layers; ++l) {
     const mtmc_layer& L = model->enc_node[l];
+    if (few) {
+      out->enc_kernel[l] = l == 0 ? MTMC_GEMM_FEW_L0 : MTMC_GEMM_FEW_WAVE;
+      out->enc_split_k[l] = 1;
+      continue;
+    }
     int sk_full = 1, sk_here = 1;
     mtmc::gemm_plan(c->n_nodes, L.in_dim, L.out_dim, &sk_full);
     const int cfg = rows > 0 ? mtmc::gemm_plan(rows, L.in_dim, L.out_dim, &sk_here) : 0;
@@ -143,6 +159,9 @@ int32_t mtmc_mpn_plan_call(const mtmc_mpn_model* model, const mtmc_mpn_call* cal
                                                          (mtmc::rows_layer(c->n_nodes, L.in_dim, L.out_dim) && mtmc::rows_layer(rows, L.in_dim, L.out_dim))));
     out->enc2_passenger = (c->n_edges > 0 && rows > 0 && c->n_edges <= (int64_t)2048 * 256 && !big_last &&
                            mtmc::gemm_plan(rows, L.in_dim, L.out_dim, &sk) == 1 && !(c->flags & MTMC_F_FORK)) ? 1 : 0;
+    if (few)
+      out->enc2_passenger = (c->n_edges > 0 && c->n_edges <= (int64_t)2048 * 256 && last >= 1 &&
+                             mtmc::few_wave_threads(L.in_dim) == 256 && !(c->flags & MTMC_F_FORK)) ? 1 : 0;
   }
   return MTMC_OK;
 }
@@ -308,6 +327,41 @@ int32_t mtmc_linear_staged_raw(const float* A, int64_t lda, const double* stats_
     g.bias = bias; g.Y = Y; g.ldy = N; g.stats_out = stats; g.amax_y = scratch + 2 * mtmc::kAmaxRep;
     g.M = M; g.K = K; g.Nout = N;
     rc = mtmc::launch_gemm_staged(g, s);
+  }
+  if (rc != 0) return fail(rc == MTMC_E_HIP ? MTMC_E_HIP : MTMC_E_ARG, "unsupported shape or launch refused");
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MTMC_OK : fail(MTMC_E_HIP, "launch failed: %s", hipGetErrorString(e));
+}
+
+// Diagnostics / unit tests: one encoder layer as the forward runs it on few-row graphs (gemm_few.hip).
+int32_t mtmc_linear_few_raw(const float* A, int64_t lda, const double* stats_in, const float* gamma_in, const float* beta_in,
+                            double count, const float* W, const float* bias, float* Y, int64_t M, int32_t K, int32_t N,
+                            void* work, uint64_t work_bytes, double* stats, void* stream) {
+  const bool l0 = stats_in == nullptr;
+  if (!A || !W || !bias || !Y || !work || M < 1 || K < 32 || K > 2048 || N < 1 || lda < K || (lda & 3) || ((uintptr_t)A & 15) ||
+      (l0 ? !mtmc::few_l0_shape(K, N) : (!mtmc::few_wave_shape(K, N) || !gamma_in || !beta_in)))
+    return fail(MTMC_E_ARG, "bad arguments");
+  const uint64_t a_bytes = l0 ? (uint64_t)M * K * 4 : 0, w_bytes = (uint64_t)N * K * 4;
+  const uint64_t ia_off = a_bytes, wh_off = (ia_off + (uint64_t)M * 4 + 255) / 256 * 256, iw_off = wh_off + w_bytes;
+  if (work_bytes < iw_off + (uint64_t)N * 4) return fail(MTMC_E_ARG, "work buffer too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (stats && hipMemsetAsync(stats, 0, 2 * (size_t)N * sizeof(double), s) != hipSuccess) return fail(MTMC_E_HIP, "hipMemsetAsync failed");
+  unsigned char* wk = static_cast<unsigned char*>(work);
+  mtmc::launch_split_rows(W, K, N, K, wk + wh_off, reinterpret_cast<float*>(wk + iw_off), s);
+  int rc;
+  if (l0) {
+    mtmc::launch_split_rows(A, lda, M, K, wk, reinterpret_cast<float*>(wk + ia_off), s);
+    mtmc::FewL0Params g;
+    g.Ah = reinterpret_cast<const _Float16*>(wk); g.inv_a = reinterpret_cast<const float*>(wk + ia_off);
+    g.Wh = reinterpret_cast<const _Float16*>(wk + wh_off); g.inv_w = reinterpret_cast<const float*>(wk + iw_off);
+    g.bias = bias; g.Y = Y; g.ldy = N; g.stats_out = stats; g.M = M; g.K = K; g.Nout = N;
+    rc = mtmc::launch_few_l0(g, s);
+  } else {
+    mtmc::FewWaveParams g;
+    g.A = A; g.lda = lda; g.stats_in = stats_in; g.gamma_in = gamma_in; g.beta_in = beta_in; g.count = count;
+    g.Wh = reinterpret_cast<const _Float16*>(wk + wh_off); g.inv_w = reinterpret_cast<const float*>(wk + iw_off);
+    g.bias = bias; g.Y = Y; g.ldy = N; g.stats_out = stats; g.M = M; g.K = K; g.Nout = N;
+    rc = mtmc::launch_few_wave(g, s);
   }
   if (rc != 0) return fail(rc == MTMC_E_HIP ? MTMC_E_HIP : MTMC_E_ARG, "unsupported shape or launch refused");
   const hipError_t e = hipGetLastError();

@@ -32,8 +32,7 @@ struct Layout {
   size_t row32, col32, e_buf[2], P, Q, slab, enc_aff, row_start, carry;
   size_t col_sub; int col_blocks;              // column-blocked pass A: int[N][col_blocks + 1] sub-run boundaries (0 blocks: none)
   size_t amax;                                 // u32[1 + 2*MTMC_MAX_ENC_LAYERS][kAmaxRep]: |x|max, -, |Y_l|max (zeroed)
-  size_t amax_w;                               // u32[MTMC_MAX_ENC_LAYERS][kAmaxRep]: |W_l|max of the in-loop layers -- the LAST
-                                               // block of the zeroed head: a call with MTMC_F_WEIGHTS_CACHED leaves it alone
+  size_t amax_w;                               // u32[MTMC_MAX_ENC_LAYERS][kAmaxRep]: |W_l|max of the in-loop layers
   size_t Y[MTMC_MAX_ENC_LAYERS];
   size_t stat_enc_layer[MTMC_MAX_ENC_LAYERS];
   // training: every round keeps its own buffers (the workspace is the backward tape) + backward scratch
@@ -41,6 +40,7 @@ struct Layout {
   std::vector<size_t> z_tr, e_tr, h_tr;       // per round: z1 [E][4], e' [E][4], aggregated h [N][32]
   std::vector<size_t> P_tr, Q_tr;             // per round: the node projections [2][N][4], [N][32]
   size_t xh, inv_a, wh, inv_w; bool presplit0;   // layer 0 on pre-split operands (many-row graphs): fp16 planes + row scales
+  bool few;                                    // few-row graphs (gemm_few.hip): xh / inv_a hold the planes of x (W: weight-plane cache)
   size_t wh_l[MTMC_MAX_ENC_LAYERS], inv_w_l[MTMC_MAX_ENC_LAYERS]; bool staged[MTMC_MAX_ENC_LAYERS];   // layers >= 1 on the
                                                // role-split kernel (gemm_staged.hip): the layer's weight planes + row scales
   size_t g_e[2], g_e0, g_h[2], g_h0, g_P, g_Q, g_de2, g_arg;   // gradients wrt e_r, e0, h_r, h0, P, Q; A^T dz2 [E][4]
@@ -51,6 +51,30 @@ struct Layout {
   size_t gA, gB, tA, tB, tW, zeros, bst_n;     // node-encoder backward: gradient ping-pong, transposes, 0-bias, column stats
 };
 constexpr int kBwdStride = 256;                // doubles per replica of the backward statistics scratch
+
+// The weight-plane cache (mtmc_mpn_call::weight_cache; split_body.h): per node-encoder layer the fp16 planes [2][K/32][out][32],
+// the inverse row scales [out] and one 64-bit fingerprint per 8-row chunk.  Depends on the model's dimensions only.
+struct CacheLayout { size_t planes[MTMC_MAX_ENC_LAYERS], inv[MTMC_MAX_ENC_LAYERS], fp[MTMC_MAX_ENC_LAYERS]; bool has[MTMC_MAX_ENC_LAYERS]; size_t total; };
+inline void make_cache_layout(const mtmc_mpn_model* m, CacheLayout* cl) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
+  for (int l = 0; l < MTMC_MAX_ENC_LAYERS; ++l) {
+    cl->has[l] = l < m->n_enc_layers && m->enc_node[l].in_dim % 8 == 0 && m->enc_node[l].in_dim <= 2048;
+    cl->planes[l] = cl->inv[l] = cl->fp[l] = 0;
+    if (!cl->has[l]) continue;
+    const size_t K = m->enc_node[l].in_dim, O = m->enc_node[l].out_dim;
+    cl->planes[l] = take(4 * O * K);
+    cl->inv[l] = take(4 * O);
+    cl->fp[l] = take(8 * ((O + 7) / 8));
+  }
+  cl->total = off;
+}
+// the node encoder's shape admits the few-row kernels for `rows` rows (gemm_few.hip; knobs included)
+inline bool few_shape(const mtmc_mpn_model* m, int64_t rows) {
+  int in_dim[MTMC_MAX_ENC_LAYERS], out_dim[MTMC_MAX_ENC_LAYERS];
+  for (int l = 0; l < m->n_enc_layers; ++l) { in_dim[l] = m->enc_node[l].in_dim; out_dim[l] = m->enc_node[l].out_dim; }
+  return mtmc::few_rows_path(rows, m->n_enc_layers, in_dim, out_dim);
+}
 
 inline int check_model(const mtmc_mpn_model* m) {
   if (!m) return fail(MTMC_E_ARG, "model is NULL");
@@ -129,12 +153,15 @@ inline void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* l
   // Layer 0 of a many-row graph runs on operands split ONCE into fp16 pairs (gemm_presplit.hip): planes of x [2][N][K]
   // and of W0 [2][out][K] plus one power-of-two scale per row.  An x-sized region; eval mode only.
   lo->presplit0 = !training && mtmc::presplit_layer0(N, m->enc_node[0].in_dim, m->enc_node[0].out_dim);
-  if (lo->presplit0) {
+  lo->few = !training && few_shape(m, N);     // (the call also needs a weight-plane cache: use_few)
+  if (lo->presplit0 || lo->few) {
     const size_t K0 = m->enc_node[0].in_dim, O0 = m->enc_node[0].out_dim;
     lo->xh = take((size_t)2 * N * K0 * sizeof(uint16_t));
     lo->inv_a = take((size_t)N * sizeof(float));
-    lo->wh = take((size_t)2 * O0 * K0 * sizeof(uint16_t));
-    lo->inv_w = take(O0 * sizeof(float));
+    if (lo->presplit0) {                       // (without a weight-plane cache the planes of W0 are made per call, here)
+      lo->wh = take((size_t)2 * O0 * K0 * sizeof(uint16_t));
+      lo->inv_w = take(O0 * sizeof(float));
+    }
   }
   for (int l = 1; l < m->n_enc_layers; ++l) {
     lo->staged[l] = !training && mtmc::staged_layer(N, m->enc_node[l].in_dim, m->enc_node[l].out_dim);
@@ -195,6 +222,9 @@ struct Ctx {
   Layout lo;
   char* ws;
   hipStream_t stream;
+  char* wc = nullptr;                // the weight-plane cache of an eval-mode call, or nullptr (training / none given)
+  CacheLayout cl;
+  template <typename T> T* wc_at(size_t off) const { return reinterpret_cast<T*>(wc + off); }
   const SidePipe* pipe = nullptr;    // set by mtmc_mpn_forward: layer 0 runs in row panels (split of panel i+1 beside GEMM i)
   bool enc2_rides = false;           // set by mtmc_mpn_forward (few-row graphs): MTMC_PH_EDGE_ENC's work rides as passenger
                                      // workgroups in the last node-encoder layer's GEMM launch instead of a launch of its own
@@ -237,6 +267,13 @@ inline int make_ctx(const mtmc_mpn_model* m, const mtmc_mpn_call* c, Ctx* ctx) {
     return fail(MTMC_E_WORKSPACE, "workspace has %zu bytes, %zu needed", c->workspace_bytes, ctx->lo.pub.total_bytes);
   ctx->ws = static_cast<char*>(c->workspace);
   ctx->stream = static_cast<hipStream_t>(c->stream);
+  make_cache_layout(m, &ctx->cl);
+  if (c->weight_cache && !c->training) {
+    if ((uintptr_t)c->weight_cache & 255) return fail(MTMC_E_WORKSPACE, "weight_cache must be 256-byte aligned");
+    if (c->weight_cache_bytes < ctx->cl.total)
+      return fail(MTMC_E_WORKSPACE, "weight_cache has %zu bytes, %zu needed (mtmc_mpn_weight_cache_bytes)", c->weight_cache_bytes, ctx->cl.total);
+    ctx->wc = static_cast<char*>(c->weight_cache);
+  }
   return MTMC_OK;
 }
 
@@ -353,6 +390,22 @@ inline bool use_rows(const Ctx& x, int l) {
          mtmc::rows_layer(x.c->node_hi - x.c->node_lo, x.m->enc_node[l].in_dim, x.m->enc_node[l].out_dim);
 }
 
+// every layer on the few-row kernels (gemm_few.hip): eval mode, a weight-plane cache, few rows here AND in the whole graph
+inline bool use_few(const Ctx& x) {
+  if (!x.lo.few || !x.wc || x.c->training) return false;
+  for (int l = 0; l < x.m->n_enc_layers; ++l) if (!x.cl.has[l]) return false;
+  return few_shape(x.m, x.c->node_hi - x.c->node_lo);
+}
+// where layer l's weight planes / inverse row scales are: the cache when the call has one, else the workspace (made per call)
+inline _Float16* w_planes(const Ctx& x, int l) {
+  if (x.wc && x.cl.has[l]) return x.wc_at<_Float16>(x.cl.planes[l]);
+  return x.at<_Float16>(l == 0 ? x.lo.wh : x.lo.wh_l[l]);
+}
+inline float* w_inv(const Ctx& x, int l) {
+  if (x.wc && x.cl.has[l]) return x.wc_at<float>(x.cl.inv[l]);
+  return x.at<float>(l == 0 ? x.lo.inv_w : x.lo.inv_w_l[l]);
+}
+
 // Row panels of the pipelined layer 0: cuts[0..np] (multiples of the tile height), np <= kMaxPanels; *bm = the tile height
 // of every panel (what the whole matrix would pick).  One round = 256 workgroups = 256 / tiles_n row tiles.
 inline int l0_panels(int64_t rows, int Nout, int64_t* cuts, int* bm) {
@@ -380,6 +433,7 @@ inline bool enc2_can_ride(const Ctx& x) {
   const int last = x.m->n_enc_layers - 1;
   const int64_t rows = x.c->node_hi - x.c->node_lo;
   if (x.c->n_edges <= 0 || rows <= 0 || x.c->n_edges > (int64_t)2048 * 256) return false;
+  if (use_few(x)) return last >= 1 && mtmc::few_wave_threads(x.m->enc_node[last].in_dim) == 256;   // (enc2_body: 256 threads)
   if ((last == 0 && use_presplit0(x)) || use_staged(x, last) || use_rows(x, last)) return false;
   int sk;
   return mtmc::gemm_plan(rows, x.m->enc_node[last].in_dim, x.m->enc_node[last].out_dim, &sk) == 1;
@@ -400,11 +454,10 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
     case MTMC_PH_BEGIN:
     case kPhMemset:
     case kPhPrep: {
-      // MTMC_F_WEIGHTS_CACHED (eval mode): everything derived from the WEIGHTS alone -- the fp16 planes + row scales of W0 and
-      // of the staged layers, the |W_l|max words of the in-loop layers -- is still in this workspace from the previous call
-      // (same weights, same sizes: the host's promise); it is neither cleared nor derived again
-      const bool w_cached = (c->flags & MTMC_F_WEIGHTS_CACHED) && !c->training;
-      if (phase != kPhPrep && hipMemsetAsync(x.ws, 0, w_cached ? x.lo.amax_w : x.lo.pub.zero_bytes, s) != hipSuccess)
+      // What depends on the WEIGHTS alone -- the fp16 planes + row scales of the layers that run on pre-split weights -- lives in
+      // the call's weight-plane cache when it has one and is VERIFIED here on every call, chunk by chunk, by passenger
+      // workgroups of prep_kernel (split_body.h); without a cache it is made per call in the workspace.
+      if (phase != kPhPrep && hipMemsetAsync(x.ws, 0, x.lo.pub.zero_bytes, s) != hipSuccess)
         return fail(MTMC_E_HIP, "hipMemsetAsync failed");
       if (phase != kPhMemset) {
         mtmc::PrepParams p;
@@ -413,16 +466,31 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
         p.row32 = x.at<int>(x.lo.row32); p.col32 = x.at<int>(x.lo.col32); p.deg = x.at<int>(x.lo.pub.deg_off);
         p.flags = x.at<int>(x.lo.pub.flags_off); p.stat_attr = x.at<double>(x.lo.pub.stat_attr_off);
         p.row_start = x.at<int>(x.lo.row_start);
-        // operand |.|max values of the node encoder ride along (this rank's rows of x; every layer's weights)
+        // passenger jobs: operand |.|max values / operand splits of the node encoder (this rank's rows of x; the weights)
         unsigned* amax = x.at<unsigned>(x.lo.amax);
         p.n_jobs = 0;
-        const bool pre0 = use_presplit0(x);
-        if (c->node_hi > c->node_lo) {
-          if (!pre0) p.jobs[p.n_jobs++] = {c->x, c->node_hi - c->node_lo, m->enc_node[0].in_dim, c->x_row_stride, amax, 0, 0};
-          for (int l = pre0 ? 1 : 0; l < m->n_enc_layers && !w_cached; ++l)
-            if (!use_staged(x, l) && !use_rows(x, l))   // (staged: weights split into planes below; row-streaming: in the kernel)
-              p.jobs[p.n_jobs++] = {m->enc_node[l].weight, m->enc_node[l].out_dim, m->enc_node[l].in_dim,
-                                    m->enc_node[l].in_dim, x.at<unsigned>(x.lo.amax_w) + l * mtmc::kAmaxRep, 0, 0};
+        const bool pre0 = use_presplit0(x), few = use_few(x);
+        const int64_t rows = c->node_hi - c->node_lo;
+        auto cache_job = [&](int l) {     // layer l's planes in the cache: verify every 8-row chunk, split the ones that changed
+          p.jobs[p.n_jobs++] = {m->enc_node[l].weight, m->enc_node[l].out_dim, m->enc_node[l].in_dim, m->enc_node[l].in_dim, nullptr, 0, 0,
+                                mtmc::kJobSplit, x.wc_at<_Float16>(x.cl.planes[l]), x.wc_at<float>(x.cl.inv[l]),
+                                x.wc_at<unsigned long long>(x.cl.fp[l])};
+        };
+        if (rows > 0) {
+          if (few)         // the planes of x, 8 rows per passenger workgroup (no |x|max: one scale per row)
+            p.jobs[p.n_jobs++] = {c->x, rows, m->enc_node[0].in_dim, c->x_row_stride, nullptr, 0, 0, mtmc::kJobSplit,
+                                  x.at<_Float16>(x.lo.xh), x.at<float>(x.lo.inv_a), nullptr};
+          else if (!pre0)
+            p.jobs[p.n_jobs++] = {c->x, rows, m->enc_node[0].in_dim, c->x_row_stride, amax, 0, 0, mtmc::kJobAmax, nullptr, nullptr, nullptr};
+          for (int l = 0; l < m->n_enc_layers; ++l) {
+            const bool planes = few || (l == 0 ? pre0 : use_staged(x, l));
+            if (planes) {
+              if (x.wc && x.cl.has[l]) cache_job(l);            // (no cache: launch_split_rows below)
+            } else if (!use_rows(x, l)) {                       // in-loop kernel: |W_l|max (row-streaming: in the kernel)
+              p.jobs[p.n_jobs++] = {m->enc_node[l].weight, m->enc_node[l].out_dim, m->enc_node[l].in_dim, m->enc_node[l].in_dim,
+                                    x.at<unsigned>(x.lo.amax_w) + l * mtmc::kAmaxRep, 0, 0, mtmc::kJobAmax, nullptr, nullptr, nullptr};
+            }
+          }
         }
         mtmc::launch_prep(p, s);
         if (L > 0 && c->n_edges > 0 && call_col_blocks(x) > 0) {   // sub-run boundaries of the column-blocked pass A, once per forward
@@ -431,15 +499,15 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
         }
         if (pre0) {     // instead of the |.|max of x and W0: their fp16 planes and row scales (one pass over each)
           if (!x.pipe)  // (pipelined layer 0: the x planes are made panel by panel in MTMC_PH_NODE_ENC 0)
-            mtmc::launch_split_rows(c->x, c->x_row_stride, c->node_hi - c->node_lo, m->enc_node[0].in_dim, x.at<void>(x.lo.xh),
+            mtmc::launch_split_rows(c->x, c->x_row_stride, rows, m->enc_node[0].in_dim, x.at<void>(x.lo.xh),
                                     x.at<float>(x.lo.inv_a), s);
-          if (!w_cached)
+          if (!(x.wc && x.cl.has[0]))
             mtmc::launch_split_rows(m->enc_node[0].weight, m->enc_node[0].in_dim, m->enc_node[0].out_dim,
                                     m->enc_node[0].in_dim, x.at<void>(x.lo.wh), x.at<float>(x.lo.inv_w), s);
         }
-        if (c->node_hi > c->node_lo && !w_cached)
+        if (rows > 0)
           for (int l = 1; l < m->n_enc_layers; ++l)
-            if (use_staged(x, l))
+            if (use_staged(x, l) && !(x.wc && x.cl.has[l]))
               mtmc::launch_split_rows(m->enc_node[l].weight, m->enc_node[l].in_dim, m->enc_node[l].out_dim,
                                       m->enc_node[l].in_dim, x.at<void>(x.lo.wh_l[l]), x.at<float>(x.lo.inv_w_l[l]), s);
       }
@@ -455,11 +523,42 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
       const int64_t rows = c->node_hi - c->node_lo;
       if (rows == 0) break;
       const mtmc_layer& Lr = m->enc_node[arg];
+      if (use_few(x)) {                                          // few-row graphs: one launch per layer, never split along K
+        if (phase == MTMC_PH_NODE_COMBINE) break;
+        int rc;
+        if (arg == 0) {
+          mtmc::FewL0Params q;
+          q.Ah = x.at<_Float16>(x.lo.xh); q.inv_a = x.at<float>(x.lo.inv_a);
+          q.Wh = w_planes(x, 0); q.inv_w = w_inv(x, 0);
+          q.bias = Lr.bias; q.Y = x.at<float>(x.lo.Y[0]); q.ldy = Lr.out_dim;
+          q.stats_out = x.at<double>(x.lo.stat_enc_layer[0]);
+          q.M = rows; q.K = Lr.in_dim; q.Nout = Lr.out_dim;
+          rc = mtmc::launch_few_l0(q, s);
+        } else {
+          mtmc::FewWaveParams q;
+          q.A = x.at<float>(x.lo.Y[arg - 1]); q.lda = m->enc_node[arg - 1].out_dim;
+          q.stats_in = x.at<double>(x.lo.stat_enc_layer[arg - 1]);
+          q.gamma_in = m->enc_node[arg - 1].gamma; q.beta_in = m->enc_node[arg - 1].beta; q.count = (double)c->n_nodes;
+          q.Wh = w_planes(x, arg); q.inv_w = w_inv(x, arg);
+          q.bias = Lr.bias; q.Y = x.at<float>(x.lo.Y[arg]); q.ldy = Lr.out_dim;
+          q.stats_out = x.at<double>(x.lo.stat_enc_layer[arg]);
+          q.M = rows; q.K = Lr.in_dim; q.Nout = Lr.out_dim;
+          if (x.enc2_rides && arg == m->n_enc_layers - 1) {
+            const int64_t blocks = (c->n_edges + 255) / 256;
+            q.pass_blocks = (int)(blocks > 2048 ? 2048 : blocks);
+            q.pass_enc = enc_params(x); q.pass_attr = c->edge_attr; q.pass_edges = c->n_edges;
+            q.pass_e_total = (double)c->n_edges_total; q.pass_stat = x.at<double>(x.lo.pub.stat_enc2_off);
+          }
+          rc = mtmc::launch_few_wave(q, s);
+        }
+        if (rc != 0) return fail(rc == MTMC_E_HIP ? MTMC_E_HIP : MTMC_E_ARG, "encoder layer %d: few-row kernel refused the shape or the launch", arg);
+        break;
+      }
       if (arg == 0 && use_presplit0(x)) {
         if (phase == MTMC_PH_NODE_COMBINE) break;                // never split along K
         mtmc::SplitGemmParams q;
         q.Ah = x.at<_Float16>(x.lo.xh); q.inv_a = x.at<float>(x.lo.inv_a);
-        q.Wh = x.at<_Float16>(x.lo.wh); q.inv_w = x.at<float>(x.lo.inv_w);
+        q.Wh = w_planes(x, 0); q.inv_w = w_inv(x, 0);
         q.bias = Lr.bias; q.Y = x.at<float>(x.lo.Y[0]); q.ldy = Lr.out_dim;
         q.stats_out = x.at<double>(x.lo.stat_enc_layer[0]);
         q.amax_y = x.at<unsigned>(x.lo.amax) + (1 + MTMC_MAX_ENC_LAYERS) * mtmc::kAmaxRep;
@@ -498,7 +597,7 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
         q.stats_in = x.at<double>(x.lo.stat_enc_layer[arg - 1]);
         q.gamma_in = m->enc_node[arg - 1].gamma; q.beta_in = m->enc_node[arg - 1].beta; q.count = (double)c->n_nodes;
         q.amax_a = amax + (1 + MTMC_MAX_ENC_LAYERS + (arg - 1)) * mtmc::kAmaxRep;
-        q.Wh = x.at<_Float16>(x.lo.wh_l[arg]); q.inv_w = x.at<float>(x.lo.inv_w_l[arg]);
+        q.Wh = w_planes(x, arg); q.inv_w = w_inv(x, arg);
         q.bias = Lr.bias; q.Y = x.at<float>(x.lo.Y[arg]); q.ldy = Lr.out_dim;
         q.stats_out = x.at<double>(x.lo.stat_enc_layer[arg]);
         q.amax_y = amax + (1 + MTMC_MAX_ENC_LAYERS + arg) * mtmc::kAmaxRep;

@@ -12,6 +12,7 @@
 //   pass_c_kernel      m = relu(bn(Wn.[h[row]|e'] + bn)); h' = agg_row(m); logits  (NodeModel, mpn.py:97-99)
 //   classify_e0_kernel logits of the encoded edges when L == 0                      (mpn.py:295-297)
 #include "kernels.h"
+#include "split_body.h"
 
 #include <type_traits>
 
@@ -25,6 +26,12 @@ __device__ void amax_jobs(const PrepParams& p, int block) {
   int j = 0;
   while (j + 1 < p.n_jobs && block >= p.jobs[j + 1].block0) ++j;      // every passenger workgroup serves ONE job
   const AmaxJob job = p.jobs[j];
+  if (job.kind == kJobSplit) {        // operand split (x planes of few-row graphs / the weight-plane cache): split_body.h
+    __shared__ unsigned long long fp_red[4];
+    split_rows_body(job.ptr, job.ld, job.rows, job.cols, job.planes, job.rows * (int64_t)job.cols, job.inv, 0, job.rows,
+                    block - job.block0, job.fp, fp_red);
+    return;
+  }
   const int c4n = job.cols / 4;                         // cols is a multiple of 32 (check_model)
   const int64_t total = job.rows * c4n;
   const bool dense = job.ld == job.cols;                // weights and contiguous x: no row arithmetic
@@ -1545,7 +1552,8 @@ void launch_prep(const PrepParams& p0, hipStream_t s) {
   for (int j = 0; j < p.n_jobs; ++j) {                  // ~16 float4 per lane, at most 2048 workgroups per operand
     const int64_t f4 = p.jobs[j].rows * (p.jobs[j].cols / 4), want = (f4 + 4095) / 4096;
     p.jobs[j].block0 = extra;
-    p.jobs[j].n_blocks = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+    p.jobs[j].n_blocks = p.jobs[j].kind == kJobSplit ? (int)((p.jobs[j].rows + 7) / 8)       // 8 rows per workgroup
+                                                     : (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
     extra += p.jobs[j].n_blocks;
   }
   if (p.n_edge_blocks + extra == 0) return;

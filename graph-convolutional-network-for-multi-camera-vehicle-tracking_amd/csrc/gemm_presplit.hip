@@ -18,6 +18,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "lds_dma.h"
+#include "split_body.h"
 
 namespace mtmc {
 
@@ -30,57 +31,7 @@ namespace mtmc {
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ X, int64_t ld, int64_t rows, int K,
                                                          _Float16* __restrict__ H, int64_t plane, float* __restrict__ inv,
                                                          int64_t r_lo, int64_t r_hi) {
-  // rows [r_lo, r_hi) of the `rows` the planes are laid out for (r_lo even: a wave's two rows share 128-byte lines)
-  const int lane = threadIdx.x & 63, l = lane & 31;
-  const int64_t row = r_lo + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
-  const bool live = row < r_hi;
-  const float* src = X + (live ? row : r_hi - 1) * ld;
-  float4 v[8][2];
-  float m = 0.f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int k = (j * 32 + l) * 8;
-    if (k < K) {
-      v[j][0] = *reinterpret_cast<const float4*>(src + k);
-      v[j][1] = *reinterpret_cast<const float4*>(src + k + 4);
-    } else {
-      v[j][0] = v[j][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[j][0].x), fabsf(v[j][0].y)), fmaxf(fabsf(v[j][0].z), fabsf(v[j][0].w))));
-    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[j][1].x), fabsf(v[j][1].y)), fmaxf(fabsf(v[j][1].z), fabsf(v[j][1].w))));
-  }
-#pragma unroll
-  for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-  if (!live) return;
-  int e = 0;
-  if (m > 0.f && m < 3e38f) (void)frexpf(m, &e);
-  e = e < -100 ? -100 : (e > 100 ? 100 : e);
-  const float s = ldexpf(1.f, 14 - e);
-  if (l == 0) inv[row] = ldexpf(1.f, e - 14);
-  _Float16* d1 = H + row * kPlaneKT;                     // + (k / kPlaneKT) * rows * kPlaneKT + swizzled slot
-  _Float16* d2 = d1 + plane;
-  const int g = (int)((row >> 2) & 3);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int k = (j * 32 + l) * 8;
-    if (k < K) {
-      uint4 q1, q2;
-      auto two = [&](float a, float b, unsigned& o1, unsigned& o2) {
-        const float x0 = a * s, x1 = b * s;
-        const h2_t h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-        const h2_t lo = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
-        o1 = __builtin_bit_cast(unsigned, h);
-        o2 = __builtin_bit_cast(unsigned, lo);
-      };
-      two(v[j][0].x, v[j][0].y, q1.x, q2.x);
-      two(v[j][0].z, v[j][0].w, q1.y, q2.y);
-      two(v[j][1].x, v[j][1].y, q1.z, q2.z);
-      two(v[j][1].z, v[j][1].w, q1.w, q2.w);
-      const int64_t o = (int64_t)(k / kPlaneKT) * rows * kPlaneKT + ((((k % kPlaneKT) >> 3) ^ g) << 3);
-      *reinterpret_cast<uint4*>(d1 + o) = q1;
-      *reinterpret_cast<uint4*>(d2 + o) = q2;
-    }
-  }
+  split_rows_body(X, ld, rows, K, H, plane, inv, r_lo, r_hi, (int)blockIdx.x, nullptr, nullptr);   // (split_body.h)
 }
 
 void launch_split_rows_range(const float* X, int64_t ld, int64_t rows, int K, void* H, float* inv, int64_t r_lo, int64_t r_hi,
@@ -151,7 +102,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16p_m16_kernel(SplitGemmParams p
   };
 
   const int r16 = lane & 15, ks = lane >> 4;                       // fragment row inside a 16-row block, 8-half k group
-  const int so = (ks ^ ((r16 >> 2) & 3)) * 16;                     // the stored swizzle: slot ^ ((row >> 2) & 3)
+  const int so = (ks ^ plane_swz(r16)) * 16;                       // the stored swizzle (lds_dma.h)
   const int a_row = (wm * 128 + r16) * ROWB + so, b_row = (wn * 64 + r16) * ROWB + so;
 
   f32x4v acc[8][4];

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(kSgNT) void gemm_staged_kernel(StagedGemmParams p, 
       const int r = r0 + 32 * h;
       const int64_t row = (r < bm && m0 + r < p.M) ? m0 + r : m0;    // rows past M or past the tile's height: the tile's
       a_src[h] = p.A + row * p.lda + c8 * 4;                         // first row again (cached; what they feed is never stored)
-      a_dst[h] = (unsigned)(r * kSgRowB + (((c8 >> 1) ^ ((r >> 2) & 3)) << 4) + (c8 & 1) * 8);   // the fragment reads' swizzle
+      a_dst[h] = (unsigned)(r * kSgRowB + (((c8 >> 1) ^ plane_swz(r)) << 4) + (c8 & 1) * 8);   // the fragment reads' swizzle
     }
     float4 ra[kSgSets][NH];                              // [register set][row]
     auto load_a = [&](int kt, int set) {
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kSgNT) void gemm_staged_kernel(StagedGemmParams p, 
       for (int g = 0; g < 2 * WJ; ++g) dma_one(kt, g);
     };
     const int r16 = lane & 15, ks = lane >> 4;                       // fragment row inside a 16-row block, 8-half k group
-    const int so = (ks ^ ((r16 >> 2) & 3)) * 16;                     // the stored swizzle: slot ^ ((row >> 2) & 3)
+    const int so = (ks ^ plane_swz(r16)) * 16;                       // the stored swizzle (lds_dma.h)
     const int wrow = wm < WM / 2 ? 64 * wm : 32 * WM + (wm - WM / 2) * xr;    // this wave's first row of the tile
     const int a_row = (wrow + r16) * kSgRowB + so, b_row = (wn * WC + r16) * kSgRowB + so;
     const int nblk = wm < WM / 2 ? 4 : xr / 16;                      // 16-row blocks of this wave

@@ -24,17 +24,24 @@ struct Knobs {
   int l0_pipeline;           // MTMC_L0_PIPELINE: layer 0 of many-row graphs in row panels, the operand split of panel i+1 on a
                              // side stream beside panel i's GEMM.  0 = off (one split pass, one GEMM), 1 = panels of
                              // 1, 2, 4, 8, 8, ... rounds of workgroups (default), 2 / 3 = uniform panels of 1 / 2 rounds
+  bool gemm_no_few;          // MTMC_GEMM_NO_FEW: few-row graphs on the split-K in-loop kernels + combine (rounds 1-4; A/B)
+  int few_rows_max;          // MTMC_FEW_ROWS_MAX: most node rows a call may encode on the few-row kernels (gemm_few.hip)
 };
 const Knobs& knobs();
 
 // |.|max of a [rows][cols] fp32 matrix (row stride ld), accumulated with atomicMax on the bit pattern: scales of the
 // fp16 two-piece node-encoder GEMM.  Done by extra workgroups of prep_kernel, i.e. without a launch of its own.
 constexpr int kAmaxRep = 16;   // replicas of every |.|max word: same-address atomics serialise in L2
-struct AmaxJob { const float* ptr; int64_t rows; int cols; int64_t ld; unsigned* out; int block0, n_blocks; };   // block range: set by launch_prep
+// kind 1 (kJobSplit): the operand split of split_body.h instead -- rows of `ptr` -> fp16 planes + row scales, 8 rows per
+// workgroup; fp != nullptr: a chunk is only split again when its 64-bit fingerprint differs from the stored one (the
+// content-verified weight-plane cache)
+enum { kJobAmax = 0, kJobSplit = 1 };
+struct AmaxJob { const float* ptr; int64_t rows; int cols; int64_t ld; unsigned* out; int block0, n_blocks;   // block range: set by launch_prep
+                 int kind; _Float16* planes; float* inv; unsigned long long* fp; };
 
 struct PrepParams {
   int n_edge_blocks, n_jobs;          // grid = n_edge_blocks + passenger blocks working through jobs[]
-  AmaxJob jobs[MTMC_MAX_ENC_LAYERS + 1];
+  AmaxJob jobs[2 * MTMC_MAX_ENC_LAYERS + 2];
   const int64_t* row; const int64_t* col; int64_t idx_stride;
   const float* attr; int fe;
   int64_t n_edges; int64_t n_nodes;
@@ -133,6 +140,36 @@ struct GemmParams {
   int pass_blocks = 0; EdgeEncParams pass_enc = {}; const float* pass_attr = nullptr; int64_t pass_edges = 0;
   double pass_e_total = 0; double* pass_stat = nullptr;
 };
+
+// Few-row graphs (gemm_few.hip): layer 0 on pre-split operands, one workgroup per 64 x 32 tile over all of K
+struct FewL0Params {
+  const _Float16* Ah; const float* inv_a;   // planes [2][K/32][M][32] of x (k-tile-major, swizzled: lds_dma.h), [M] inverse row scales
+  const _Float16* Wh; const float* inv_w;   // planes [2][K/32][Nout][32] of W0, [Nout]
+  const float* bias;
+  float* Y; int64_t ldy;
+  double* stats_out;                        // f64[2*Nout], accumulated atomically (or nullptr)
+  int64_t M; int K; int Nout;
+};
+// ... layers >= 1: 16 rows x 16 / 32 columns per workgroup, K cut between its waves
+struct FewWaveParams {
+  const float* A; int64_t lda;              // [M][K] raw Y of the previous layer
+  const double* stats_in; const float* gamma_in; const float* beta_in; double count;   // its column statistics / BatchNorm
+  const _Float16* Wh; const float* inv_w;   // planes [2][K/32][Nout][32], [Nout]
+  const float* bias;
+  float* Y; int64_t ldy;
+  double* stats_out;                        // f64[2*Nout], accumulated atomically (or nullptr)
+  int64_t M; int K; int Nout;
+  int tiles = 0;                            // set by launch_few_wave
+  // passenger workgroups as in GemmParams (the edge encoder's enc2 job rides in the last layer's launch)
+  int pass_blocks = 0; EdgeEncParams pass_enc = {}; const float* pass_attr = nullptr; int64_t pass_edges = 0;
+  double pass_e_total = 0; double* pass_stat = nullptr;
+};
+bool few_l0_shape(int K, int Nout);
+bool few_wave_shape(int K, int Nout);
+int few_wave_threads(int K);                // threads per workgroup launch_few_wave uses for a layer of depth K
+bool few_rows_path(int64_t rows, int n_layers, const int* in_dim, const int* out_dim);
+int launch_few_l0(const FewL0Params& p, hipStream_t s);       // 0 ok, 1 unsupported shape, MTMC_E_HIP
+int launch_few_wave(const FewWaveParams& p, hipStream_t s);   // 0 ok, 1 unsupported shape
 
 // First encoder layer on pre-split operands (gemm_presplit.hip): fp16 planes [2][rows][K] and one power-of-two
 // inverse scale per row, written by launch_split_rows.

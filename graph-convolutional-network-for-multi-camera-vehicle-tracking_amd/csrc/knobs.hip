@@ -27,6 +27,8 @@ static Knobs read_knobs() {
   k.l0_pipeline = (int)num("MTMC_L0_PIPELINE", 1);
   k.no_col_blocks = on("MTMC_NO_COL_BLOCKS");
   k.col_blocks = (int)num("MTMC_COL_BLOCKS", 0);
+  k.gemm_no_few = on("MTMC_GEMM_NO_FEW");
+  k.few_rows_max = (int)num("MTMC_FEW_ROWS_MAX", 1024);
   return k;
 }
 

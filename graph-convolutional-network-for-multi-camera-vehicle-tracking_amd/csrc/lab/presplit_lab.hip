@@ -20,7 +20,7 @@ namespace mtmc {
 // LDS-DMA in lane order (16-byte chunk c of the image lands at byte 16*c), so the bank swizzle is applied to the
 // SOURCE address: chunk `sp` of row r holds the row's 16-byte slot sp ^ g(r); the fragment reads apply the same XOR.
 //   BK = 64 (128-byte rows, two rows per 256-byte bank row):  g(r) = (r >> 1) & 7
-//   BK = 32 ( 64-byte rows, four rows per bank row):          g(r) = (r >> 2) & 3
+//   BK = 32 ( 64-byte rows, four rows per bank row):          g(r) = plane_swz(r) (lds_dma.h; rounds 2-4: (r >> 2) & 3)
 //   BK = 16 ( 32-byte rows, eight rows per bank row):         g(r) = (r >> 3) & 1
 // With these every 16-lane group of a ds_read_b128 (MI355X_MICROARCH.md, LDS) touches 16 distinct slots.
 // ------------------------------------------------------------------------------------------------
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(BT * 2, MINB) void gemm_f16p_kernel(SplitGemmParams
 
   // ---- fragment reads: lane l takes row (l & 31), 16-byte slot 2*ks + (l >> 5) of the wave's 32-row blocks
   const int fr = lane & 31, hi = lane >> 5;
-  const int gl = BK == 64 ? ((fr >> 1) & 7) : (BK == 32 ? ((fr >> 2) & 3) : ((fr >> 3) & 1));
+  const int gl = BK == 64 ? ((fr >> 1) & 7) : (BK == 32 ? plane_swz(fr) : ((fr >> 3) & 1));
   const int a_row = (wm * TI * 32 + fr) * ROWB, b_row = (wn * 64 + fr) * ROWB;
   const int sx = (hi ^ gl) * 16;                                  // slot (2*ks + hi) ^ gl = (2*ks) ^ (hi ^ gl)
 
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16p_mid_kernel(SplitGemmParams p
     for (int g = 0; g < 8; ++g) issue_one(kt, buf, g);
   };
   const int fr = lane & 31, hi = lane >> 5;
-  const int gl = (fr >> 2) & 3;
+  const int gl = plane_swz(fr);
   const int a_row = (wm * TI * 32 + fr) * ROWB, b_row = (wn * 64 + fr) * ROWB;
   const int sx = (hi ^ gl) * 16;
 
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16p_pp_kernel(SplitGemmParams p,
     for (int g = 0; g < 8; ++g) issue_one(kt, g);
   };
   const int fr = lane & 31, hi = lane >> 5;
-  const int gl = (fr >> 2) & 3;
+  const int gl = plane_swz(fr);
   const int a_row = (wm * TI * 32 + fr) * ROWB, b_row = (wn * 64 + fr) * ROWB;
   const int sx = (hi ^ gl) * 16;
 

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kS2NT) void gemm_staged_w_kernel(StagedGemmParams p
       const int r = r0 + 32 * h;
       const int64_t row = (r < bm && m0 + r < p.M) ? m0 + r : m0;    // rows past M or the tile's height: the tile's first row
       a_src[h] = p.A + row * p.lda + c8 * 4;                         // again (cached; what they feed is never stored)
-      a_dst[h] = (unsigned)(r * kS2RowB + (((c8 >> 1) ^ ((r >> 2) & 3)) << 4) + (c8 & 1) * 8);
+      a_dst[h] = (unsigned)(r * kS2RowB + (((c8 >> 1) ^ plane_swz(r)) << 4) + (c8 & 1) * 8);
     }
     float4 ra[kS2Sets][4];
     auto load_a = [&](int kt, int set) {
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kS2NT) void gemm_staged_w_kernel(StagedGemmParams p
     // rows.  W fragments: global -> registers, one k-tile ahead; A fragments: LDS, two blocks ahead.
     const int cw = wid - 4;
     const int r16 = lane & 15, ks = lane >> 4;                       // fragment row inside a 16-row block, 8-half k group
-    const int so = (ks ^ ((r16 >> 2) & 3)) * 16;                     // the stored swizzle: slot ^ ((row >> 2) & 3)
+    const int so = (ks ^ plane_swz(r16)) * 16;                       // the stored swizzle (lds_dma.h)
     const int a_row = r16 * kS2RowB + so;
     // this lane's 16 bytes of the (column block j, piece q) fragment of k-tile kt: planes are [piece][k-tile][Nout][32]
     const int64_t w_plane = (int64_t)p.Nout * p.K * 2, w_kt = (int64_t)p.Nout * kS2BK * 2;

@@ -1,0 +1,118 @@
+// The operand split of the pre-split GEMM kernels as a device function: 8 rows per 256-thread workgroup, half a wave per
+// row.  Three users: split_rows_kernel (gemm_presplit.hip: x and weights of many-row graphs), and two kinds of passenger
+// workgroups of prep_kernel (edge_kernels.hip): the x planes of few-row graphs, and the CONTENT-VERIFIED weight-plane cache.
+//
+// Weight-plane cache (round 5; replaces the host-side (data_ptr, _version) key of round 4, which writes through
+// `param.data` and recycled allocations could fool): the fp16 planes + row scales of the node-encoder weights live in a
+// buffer of the caller's that survives from forward to forward.  Every eval-mode forward re-reads the fp32 weights
+// (10.8 MB for the reference model, in workgroups that ride in prep_kernel's launch) and, per 8-row chunk, compares a 64-bit
+// fingerprint of the chunk's bits with the one stored beside the planes; only a chunk whose fingerprint differs is split
+// and stored again.  Nothing on the host decides validity, so there is no stale state to get wrong: a changed weight
+// changes the fingerprint of its chunk (any single changed word always does: the per-word multipliers are odd, hence
+// invertible mod 2^64; several changed words collide with probability 2^-63).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "lds_dma.h"
+
+namespace mtmc {
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int off) {
+  const unsigned lo = __shfl_xor((unsigned)v, off, 64), hi = __shfl_xor((unsigned)(v >> 32), off, 64);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// rows [r_lo, r_hi) of the `rows` the planes are laid out for (r_lo even: a wave's two rows share 128-byte lines);
+// `chunk` = the workgroup's index inside the job (8 rows each).  fp != nullptr: verify first, store only on a mismatch.
+// smem: 4 x u64 (only used with fp).  K <= 2048, K % 8 == 0.
+__device__ __forceinline__ void split_rows_body(const float* __restrict__ X, int64_t ld, int64_t rows, int K,
+                                                _Float16* __restrict__ H, int64_t plane, float* __restrict__ inv,
+                                                int64_t r_lo, int64_t r_hi, int chunk, unsigned long long* __restrict__ fp,
+                                                unsigned long long* smem) {
+  const int lane = threadIdx.x & 63, l = lane & 31;
+  const int64_t row = r_lo + ((int64_t)chunk * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+  const bool live = row < r_hi;
+  const float* src = X + (live ? row : r_hi - 1) * ld;
+  unsigned long long stored = 0;
+  if (fp) stored = fp[chunk];
+  float4 v[8][2];
+  float m = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = (j * 32 + l) * 8;
+    if (k < K) {
+      v[j][0] = *reinterpret_cast<const float4*>(src + k);
+      v[j][1] = *reinterpret_cast<const float4*>(src + k + 4);
+    } else {
+      v[j][0] = v[j][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[j][0].x), fabsf(v[j][0].y)), fmaxf(fabsf(v[j][0].z), fabsf(v[j][0].w))));
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[j][1].x), fabsf(v[j][1].y)), fmaxf(fabsf(v[j][1].z), fabsf(v[j][1].w))));
+  }
+  unsigned long long mine = 0;
+  if (fp) {
+    // linear hash over Z / 2^64 with an odd multiplier per position: (word index in the lane) x (thread in the workgroup)
+    unsigned long long h = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const unsigned w[4] = {__float_as_uint(v[j][q].x), __float_as_uint(v[j][q].y), __float_as_uint(v[j][q].z),
+                               __float_as_uint(v[j][q].w)};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          h += (unsigned long long)w[t] * (0x9E3779B97F4A7C15ull * (unsigned long long)(2 * ((j * 2 + q) * 4 + t) + 1) | 1ull);
+      }
+    h = live ? h * ((0xD6E8FEB86659FD93ull * (unsigned long long)(2 * threadIdx.x + 1)) | 1ull) : 0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) h += shfl_xor_u64(h, off);
+    if (lane == 0) smem[threadIdx.x >> 6] = h;
+    __syncthreads();
+    mine = smem[0] + smem[1] + smem[2] + smem[3];
+    mine ^= mine >> 29;
+    mine = (mine * 0xBF58476D1CE4E5B9ull) | 1ull;                     // never 0: a zero-filled cache holds no valid chunk
+    if (mine == stored) return;                                        // (workgroup-uniform)
+  }
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if (live) {
+    int e = 0;
+    if (m > 0.f && m < 3e38f) (void)frexpf(m, &e);
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    const float s = ldexpf(1.f, 14 - e);
+    if (l == 0) inv[row] = ldexpf(1.f, e - 14);
+    _Float16* d1 = H + row * kPlaneKT;                     // + (k / kPlaneKT) * rows * kPlaneKT + swizzled slot
+    _Float16* d2 = d1 + plane;
+    const int g = plane_swz((int)(row & 15));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = (j * 32 + l) * 8;
+      if (k < K) {
+        uint4 q1, q2;
+        auto two = [&](float a, float b, unsigned& o1, unsigned& o2) {
+          const float x0 = a * s, x1 = b * s;
+          const h2_t h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+          const h2_t lo = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
+          o1 = __builtin_bit_cast(unsigned, h);
+          o2 = __builtin_bit_cast(unsigned, lo);
+        };
+        two(v[j][0].x, v[j][0].y, q1.x, q2.x);
+        two(v[j][0].z, v[j][0].w, q1.y, q2.y);
+        two(v[j][1].x, v[j][1].y, q1.z, q2.z);
+        two(v[j][1].z, v[j][1].w, q1.w, q2.w);
+        const int64_t o = (int64_t)(k / kPlaneKT) * rows * kPlaneKT + ((((k % kPlaneKT) >> 3) ^ g) << 3);
+        *reinterpret_cast<uint4*>(d1 + o) = q1;
+        *reinterpret_cast<uint4*>(d2 + o) = q2;
+      }
+    }
+  }
+  // the fingerprint goes out with the planes: both are visible to the next kernel on the stream, and a forward that is cut
+  // off between them can only leave a chunk that is derived again (planes without their fingerprint), never the reverse --
+  // the stores above are issued first and one lane publishes the word after the workgroup's barrier
+  if (fp) {
+    __syncthreads();
+    if (threadIdx.x == 0) fp[chunk] = mine;
+  }
+}
+
+}  // namespace mtmc

@@ -94,8 +94,8 @@ class ForwardEngine:
         self._ws = {}
         self._slots = layer_slots(self.spec)
         self._ms_key, self._ms = None, None
-        self._wkeys = {}                # workspace pointer -> what its weight-derived regions were computed from
-        self.weight_cache = True        # MTMC_F_WEIGHTS_CACHED where valid (torch_ops.NO_WEIGHT_CACHE / module.cache_weight_planes)
+        self._wc = {}                   # (device, stream) -> the weight-plane cache buffer of eval-mode calls on that stream
+        self.weight_cache = True        # hand the library a weight-plane cache (torch_ops.NO_WEIGHT_CACHE / module.cache_weight_planes)
         self.flags = 0                  # MTMC_F_* for the calls this engine prepares (torch op argument)
 
     # -- parameters -> mtmc_mpn_model ------------------------------------------------------------
@@ -172,24 +172,21 @@ class ForwardEngine:
             self._ws[key] = ws
         return ws
 
-    def _weights_cached(self, ws, params, sizes) -> bool:
-        """MTMC_F_WEIGHTS_CACHED: True when the LAST call on this workspace derived its weight-only regions (fp16 planes /
-        row scales / |W|max of the node-encoder weights) from the same parameter storage at the same version and for the
-        same sizes -- the library then skips deriving them again.  In-place updates (optimizer.step, copy_, load_state_dict)
-        bump `_version`; a replaced Parameter has another pointer; a graph capture never uses the cache (the weights may
-        change between replays)."""
-        params = self.params() if params is None else params
-        n_enc = len(self.spec.enc_node)
-        key = (sizes,) + tuple((params[4 * l].data_ptr(), params[4 * l]._version) for l in range(n_enc))
-        slot = ws.data_ptr()
-        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
-            self._wkeys.pop(slot, None)
-            return False
-        hit = self._wkeys.get(slot) == key
-        if len(self._wkeys) > 64:                       # (workspaces come and go with graph sizes)
-            self._wkeys.clear()
-        self._wkeys[slot] = key
-        return hit
+    def weight_plane_cache(self, model, dev, stream_ptr) -> torch.Tensor:
+        """mtmc_mpn_call::weight_cache: a zero-filled buffer per (device, stream) in which the library keeps the fp16 planes /
+        row scales it derives from the node-encoder weights.  NOTHING here decides whether its content is still valid: every
+        eval-mode forward re-reads the weights on the device and compares a 64-bit fingerprint per 8 weight rows with the one
+        stored beside the planes (csrc/split_body.h), so in-place updates, writes through `param.data`, another module of the
+        same configuration at recycled addresses and graph replays after a weight change all get the planes of the weights
+        they run with (round 4 keyed the cache on (data_ptr, _version) on the host)."""
+        key = (dev, stream_ptr)
+        buf = self._wc.get(key)
+        if buf is None:
+            need = self.lib.mtmc_mpn_weight_cache_bytes(C.byref(model))
+            if need == 0:
+                _lib.check(_lib.E_ARG)
+            buf = self._wc[key] = torch.zeros(need + 256, dtype=torch.uint8, device=dev)
+        return buf
 
     # -- the call -----------------------------------------------------------------------------------
     def check_inputs(self, x, edge_index, edge_attr):
@@ -266,15 +263,17 @@ class ForwardEngine:
         call.workspace, call.workspace_bytes = ws.data_ptr(), ws.numel()
         call.training, call.seed = (1 if tape else 0), int(seed) & 0xFFFFFFFFFFFFFFFF
         call.flags = int(self.flags) | (_lib.F_DETERMINISTIC if getattr(self.module, "deterministic", False) else 0)
-        if self.weight_cache and not tape and tape_ws is None and self._weights_cached(ws, params, (n, e, node_lo, node_hi)):
-            call.flags |= _lib.F_WEIGHTS_CACHED
-        call.stream = stream
         keep = (x, edge_index, edge_attr)        # the structs hold raw pointers: keep the tensors alive
+        if self.weight_cache and not tape and tape_ws is None:
+            wc = self.weight_plane_cache(model, dev, stream)
+            call.weight_cache, call.weight_cache_bytes = wc.data_ptr(), wc.numel()
+            keep = keep + (wc,)
+        call.stream = stream
         return types.SimpleNamespace(model=model, call=call, ws=ws, logits=logits, h=h, n_out=n_out, n=n, e=e,
                                      dev=dev, keep=keep)
 
     def plan(self, n_nodes, n_edges, n_edges_total=None, node_range=None, row_range=None, training=False, flags=0,
-             params=None, device=None) -> types.SimpleNamespace:
+             params=None, device=None, weight_cache=True) -> types.SimpleNamespace:
         """Which kernels a call of these sizes would run (mtmc_mpn_plan_call: host-only, nothing is launched and no GPU
         is needed) -- lets a multi-GPU host, or a test, check that a shard takes the kernels the whole graph would."""
         params = self.params() if params is None else params
@@ -287,6 +286,8 @@ class ForwardEngine:
             rlo, rhi = int(row_range[0]), int(row_range[1])
             call.row_lo, call.row_hi = (rlo, rhi) if rhi > rlo else (max(rlo, 1), max(rlo, 1))
         call.training, call.flags = int(bool(training)), int(flags)
+        if weight_cache and not training:              # (tested for NULL by the query, never read)
+            call.weight_cache, call.weight_cache_bytes = 256, 1 << 62
         out = _lib.Plan()
         _lib.check(self.lib.mtmc_mpn_plan_call(C.byref(model), C.byref(call), C.byref(out)))
         n_layers = len(self.spec.enc_node)
@@ -320,7 +321,7 @@ class ForwardEngine:
             _lib.check(self.lib.mtmc_mpn_run_phases(C.byref(prep.model), C.byref(prep.call), flat, len(pairs)))
 
     def set_flags(self, prep, flags):
-        prep.call.flags = (prep.call.flags & _lib.F_WEIGHTS_CACHED) | int(flags)
+        prep.call.flags = int(flags)
 
     def region(self, prep, name, idx=0) -> torch.Tensor:
         """A tensor aliasing one exchanged region of the workspace (include/mtmc_mpn.h, mtmc_ws_layout)."""

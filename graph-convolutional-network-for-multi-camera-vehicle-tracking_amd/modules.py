@@ -123,9 +123,10 @@ class MOTMPNet(nn.Module):
         self.num_class_steps = s.num_class_steps
         self.check_indices = False          # True: synchronise and raise IndexError on out-of-range edge_index
         self.deterministic = False          # True: order-independent sum/mean aggregation on row-sorted edge lists
-        # Eval mode: what a forward derives from the node-encoder WEIGHTS alone (fp16 planes / |W|max) is reused by the next
-        # forward of the same size while the parameters' storage and `_version` are unchanged (optimizer steps, copy_ and
-        # load_state_dict bump it).  Writes through `param.data` are invisible to `_version`: set this to False if you do that.
+        # Eval mode: the fp16 operand planes of the node-encoder WEIGHTS are kept from one forward to the next in a buffer the
+        # library verifies against the weights' content on the device on every call (64-bit fingerprints per 8 weight rows,
+        # engine.weight_plane_cache): any way of changing a weight -- optimizer steps, `param.data` writes, a new module at the
+        # old addresses -- is seen.  False: no cache (few-row graphs then run the split-K kernels of rounds 1-4).
         self.cache_weight_planes = True
         self._engine = None
 
@@ -145,19 +146,18 @@ class MOTMPNet(nn.Module):
             op_engine = torch_ops.engine_for(self._config_key)
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):                 # warm-up outside the capture: lazy library setup
-                self.forward(data)
-            torch.cuda.current_stream(dev).wait_stream(side)
+            with torch.cuda.stream(side):                 # warm-up outside the capture: lazy library setup, and the workspace +
+                self.forward(data)                        # weight-plane cache of this stream exist (and are verified) before it
             side.synchronize()
-            # the warm-up's workspace is keyed by the side stream, which nothing uses again: drop it (it leaked before)
-            op_engine._ws.pop((dev, side.cuda_stream), None)
-            before = dict(op_engine._ws)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, stream=side):    # captured on the SAME stream: nothing of the engine's is allocated inside
                 out = self.forward(data)
-            # the workspace the captured kernels write to must live exactly as long as the graph: take it out of the
-            # engine's per-stream cache (a later, larger forward on that stream would otherwise replace and free it)
-            held = [op_engine._ws.pop(k) for k in list(op_engine._ws) if before.get(k) is not op_engine._ws[k]]
+            torch.cuda.current_stream(dev).wait_stream(side)
+            # the buffers the captured kernels use must live exactly as long as the graph: take them out of the engine's
+            # per-stream dictionaries (nothing else uses this stream; a later, larger forward would otherwise replace them)
+            key = (dev, side.cuda_stream)
+            held = [buf for buf in (op_engine._ws.pop(key, None), op_engine._wc.pop(key, None)) if buf is not None]
+            held.append(side)
 
         def replay():
             graph.replay()

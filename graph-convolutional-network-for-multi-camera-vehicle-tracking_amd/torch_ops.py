@@ -30,7 +30,7 @@ from . import _lib
 from . import config as _config
 
 CHECK_INDICES = 1 << 16          # host-side flag bit of `flags`: synchronise and raise IndexError on bad edge_index
-NO_WEIGHT_CACHE = 1 << 17        # host-side: never reuse the weight-derived workspace regions of the previous call
+NO_WEIGHT_CACHE = 1 << 17        # host-side: no weight-plane cache for this call (engine.weight_plane_cache)
 _ENGINES = {}
 
 

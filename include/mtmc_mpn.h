@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MTMC_MPN_ABI_VERSION 5
+#define MTMC_MPN_ABI_VERSION 6
 
 #define MTMC_MAX_ENC_LAYERS 8   /* hidden layers of the node encoder MLP          */
 #define MTMC_NODE_DIM 32        /* H : width of the node state the kernels are built for */
@@ -115,16 +115,21 @@ typedef struct mtmc_mpn_call {
   int64_t row_lo, row_hi;    /* multi-GPU, row-complete edge shards: MTMC_PH_ROUND_PROJ / _STAT work on node rows
                                 [row_lo,row_hi) only -- the source rows of this call's edges; the host then exchanges
                                 the column projections (mtmc_ws_layout.P_off) instead of the node state.  0,0 = all */
+  void* weight_cache;        /* eval mode, optional (NULL = none): >= mtmc_mpn_weight_cache_bytes() of device memory, 256-byte
+                                aligned, ZERO-FILLED once by the caller and then left alone between calls.  The library keeps
+                                what it derives from the node-encoder WEIGHTS alone in it (fp16 operand planes, row scales) and
+                                verifies it against the weights' CONTENT on every call -- a 64-bit fingerprint per 8 weight rows,
+                                taken on the device -- so the caller promises nothing about the weights: a changed weight is
+                                split again, an unchanged one is not.  One cache per stream that runs forwards concurrently.
+                                Few-row graphs need it for the kernels of csrc/gemm_few.hip (without: the split-K kernels).   */
+  size_t weight_cache_bytes;
 } mtmc_mpn_call;
 
 #define MTMC_F_DETERMINISTIC 1   /* row-sorted edge lists: sum/mean aggregation through per-chunk partials added in
                                     a fixed order instead of float atomics (bitwise run-to-run reproducible h) */
 #define MTMC_F_GLOBAL_DEG 4      /* mean aggregation divides by workspace deg_global (multi-GPU) instead of deg */
-#define MTMC_F_WEIGHTS_CACHED 8   /* eval mode: this workspace still holds what the previous call derived from the weights alone
-                                    (fp16 planes and row scales of the pre-split / staged encoder layers, |W|max of the others)
-                                    and the caller promises SAME weight values, SAME n_nodes / n_edges / node range: they are
-                                    not derived again (-3 launches per many-row forward).  Never set it for the first call on a
-                                    workspace, after any other call on it, or while capturing a graph whose weights may change */
+/* (8 was MTMC_F_WEIGHTS_CACHED in ABI v5: a host-side promise that the weights had not changed.  Gone: the weight-plane
+ * cache verifies itself, mtmc_mpn_call::weight_cache.) */
 #define MTMC_F_FORK 2            /* run the edge branch (prep, edge-encoder moments) on an internal side stream
                                     beside the node-encoder GEMMs, joined by events (default: one stream) */
 
@@ -179,6 +184,7 @@ enum {                       /* phases in forward order; `arg` = encoder layer o
 int32_t mtmc_mpn_abi_version(void);
 const char* mtmc_mpn_last_error(void);
 size_t mtmc_mpn_workspace_bytes(const mtmc_mpn_model* model, int64_t n_nodes, int64_t n_edges);
+size_t mtmc_mpn_weight_cache_bytes(const mtmc_mpn_model* model);   /* size of mtmc_mpn_call::weight_cache (0: bad model) */
 int32_t mtmc_mpn_workspace_layout(const mtmc_mpn_model* model, int64_t n_nodes, int64_t n_edges,
                                   mtmc_ws_layout* out);
 int32_t mtmc_mpn_forward(const mtmc_mpn_model* model, const mtmc_mpn_call* call);
@@ -215,13 +221,16 @@ int32_t mtmc_mpn_run_phases(const mtmc_mpn_model* model, const mtmc_mpn_call* ca
  * sizes, ranges, flags and `training`), so that a multi-GPU host or a test can check that a SHARD takes the kernels the
  * whole graph would.  Encoder layers are planned for the node_hi - node_lo rows the call encodes. */
 enum { MTMC_GEMM_GENERIC = 0, MTMC_GEMM_INLOOP_64 = 1, MTMC_GEMM_INLOOP_128 = 2, MTMC_GEMM_PRESPLIT_256 = 3,
-       MTMC_GEMM_STAGED_128 = 4, MTMC_GEMM_ROWS_16 = 5 };
+       MTMC_GEMM_STAGED_128 = 4, MTMC_GEMM_ROWS_16 = 5, MTMC_GEMM_FEW_L0 = 6, MTMC_GEMM_FEW_WAVE = 7 };
 enum { MTMC_PASS_C_WALK = 0, MTMC_PASS_C_MFMA_SORTED = 1, MTMC_PASS_C_MFMA_ANY = 2 };
 typedef struct mtmc_mpn_plan {
   int32_t enc_kernel[MTMC_MAX_ENC_LAYERS];   /* MTMC_GEMM_*: one-thread-per-output fallback / in-loop operand split on
                                                 64x64 or 128x128 tiles / pre-split fp16 planes + 256x256 tiles / (layers
                                                 >= 1 of many-row graphs) 128 x 256 or 256 x 128 tiles staged by producer waves /
-                                                (narrow last layers of many-row graphs) one wave per 16 rows         */
+                                                (narrow last layers of many-row graphs) one wave per 16 rows /
+                                                (few-row graphs with a weight-plane cache: the call's weight_cache pointer is
+                                                tested for NULL, never read) layer 0 on pre-split operands in 64 x 32 tiles over
+                                                all of K / later layers with K cut between the waves of a workgroup   */
   int32_t enc_split_k[MTMC_MAX_ENC_LAYERS];  /* K slices (few-row layers; > 1 => MTMC_PH_NODE_COMBINE does work)    */
   int32_t edges_per_thread;                  /* passes A / B                                                        */
   int32_t lazy_edges;                        /* 1: e' is never stored, consumers recompute it from z1               */
@@ -267,6 +276,14 @@ int32_t mtmc_mlp_layer_forward(const mtmc_layer* layer, const float* x, int64_t 
  * K a multiple of 32.  scratch: u32[48]; stats: f64[2*N] column sum / sum of squares of Y, or NULL. */
 int32_t mtmc_linear_raw(const float* A, int64_t lda, const float* W, const float* bias, float* Y, int64_t M, int32_t K,
                         int32_t N, uint32_t* scratch, double* stats, void* stream);
+
+/* One encoder layer as the forward runs it on FEW-ROW graphs (csrc/gemm_few.hip): stats_in == NULL: layer 0,
+ * Y = A . W^T + bias with both operands split into fp16 planes first (K a multiple of 64, <= 2048; N a multiple of 32);
+ * else a later layer, Y = relu(bn(A)) . W^T + bias as in mtmc_linear_staged_raw (K a multiple of 32; N a multiple of 16).
+ * work: >= 4*M*K + 4*N*K + 4*(M+N) + 1024 bytes; stats: f64[2*N] or NULL. */
+int32_t mtmc_linear_few_raw(const float* A, int64_t lda, const double* stats_in, const float* gamma_in, const float* beta_in,
+                            double count, const float* W, const float* bias, float* Y, int64_t M, int32_t K, int32_t N,
+                            void* work, uint64_t work_bytes, double* stats, void* stream);
 
 /* One encoder layer >= 1 as the forward runs it on many-row graphs (csrc/gemm_staged.hip: role-split kernel, N a multiple
  * of 256 or N = 128; csrc/gemm_rows.hip: row-streaming kernel for the narrow last layer, K = 128 and N = 32):

@@ -22,7 +22,8 @@ static void* upload(const void* src, size_t bytes) {
 }
 
 int main(int argc, char** argv) {
-  if (argc != 3) { fprintf(stderr, "usage: %s in.bin out.bin\n", argv[0]); return 1; }
+  if (argc != 3 && argc != 4) { fprintf(stderr, "usage: %s in.bin out.bin [cache]\n", argv[0]); return 1; }
+  const bool with_cache = argc == 4;     // a weight-plane cache (ABI v6): few-row graphs then run csrc/gemm_few.hip's kernels
   FILE* f = fopen(argv[1], "rb");
   if (!f) return 1;
   int64_t hdr[6];
@@ -78,7 +79,13 @@ int main(int argc, char** argv) {
   c.x = d_x; c.x_row_stride = F; c.row = d_ei; c.col = d_ei + E; c.idx_stride = 1; c.edge_attr = d_attr;
   c.n_nodes = N; c.n_edges = E; c.n_edges_total = E; c.node_lo = 0; c.node_hi = N;
   c.logits = d_logits; c.h_out = d_h; c.workspace = ws; c.workspace_bytes = ws_bytes; c.stream = nullptr;
-  const int rc = mtmc_mpn_forward(&m, &c);
+  if (with_cache) {
+    c.weight_cache_bytes = mtmc_mpn_weight_cache_bytes(&m);
+    CHECK(hipMalloc(&c.weight_cache, c.weight_cache_bytes));
+    CHECK(hipMemset(c.weight_cache, 0, c.weight_cache_bytes));          // zero-filled once; the library verifies it per call
+    if (mtmc_mpn_forward(&m, &c) != MTMC_OK) { fprintf(stderr, "first forward: %s\n", mtmc_mpn_last_error()); return 3; }
+  }
+  const int rc = mtmc_mpn_forward(&m, &c);                              // (with a cache: the second call, every chunk verified)
   if (rc != MTMC_OK) { fprintf(stderr, "mtmc_mpn_forward: %d (%s)\n", rc, mtmc_mpn_last_error()); return 3; }
   CHECK(hipDeviceSynchronize());
   std::vector<float> logits(n_out * E * 2), h(N * 32);

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     assert set(_lib.EXPORTS) <= declared
     lib.mtmc_mpn_abi_version.restype = ctypes.c_int32
-    assert lib.mtmc_mpn_abi_version() == 5
+    assert lib.mtmc_mpn_abi_version() == 6
 
 
 def test_workspace_sizing_needs_no_gpu():

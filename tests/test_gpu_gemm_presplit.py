@@ -133,7 +133,8 @@ def test_presplit_rejects_bad_shapes():
 @pytest.mark.parametrize("M,K", [(77, 64), (1030, 512), (4097, 2048)])
 def test_plane_layout_and_split_are_as_documented(M, K):
     """The fp16 planes in `work` follow the layout csrc/gemm_presplit.hip documents (kPlaneKT note): the eight halves
-    k..k+7 of row r sit at ((k/32)*rows + r)*32 + 8*(((k%32)/8) ^ ((r>>2)&3)); h1 + h2 reproduce x * 2^(14-e) to 22 bits
+    k..k+7 of row r sit at ((k/32)*rows + r)*32 + 8*(((k%32)/8) ^ swz(r)), swz(r) = {0, 2, 3, 1}[(r>>2)&3] (round 5: the
+    permutation that makes the 16 x 16 x 32 fragment read conflict-free, lds_dma.h); h1 + h2 reproduce x * 2^(14-e) to 22 bits
     and inv[r] = 2^(e-14) with 2^(e-1) <= max|row| < 2^e."""
     from mtmc_mpn import _lib
     lib = _lib.load()
@@ -145,7 +146,8 @@ def test_plane_layout_and_split_are_as_documented(M, K):
     planes = work[:M * K * 4].view(torch.float16).view(2, K // 32, M, 4, 8)      # [piece][k-tile][row][slot][8]
     inv = work[M * K * 4:M * K * 4 + M * 4].view(torch.float32)
     r = torch.arange(M, device="cuda")
-    slot = torch.arange(4, device="cuda").unsqueeze(0) ^ ((r >> 2) & 3).unsqueeze(1)          # [row][logical slot] -> stored slot
+    swz = torch.tensor([0, 2, 3, 1], device="cuda")[(r >> 2) & 3]
+    slot = torch.arange(4, device="cuda").unsqueeze(0) ^ swz.unsqueeze(1)                     # [row][logical slot] -> stored slot
     idx = slot.view(1, 1, M, 4, 1).expand(2, K // 32, M, 4, 8)
     logical = torch.gather(planes, 3, idx)                       # [piece][k-tile][row][logical slot][8]
     h = logical.permute(0, 2, 1, 3, 4).reshape(2, M, K).double()

@@ -88,7 +88,7 @@ def test_tracker_scale_s02_against_fp64_oracle(tracker, L, Cs):
     m, sd, params = _model(L, Cs)
     plan = engine.ForwardEngine(m).plan(1002, 751_202)
     assert plan.pass_c == _lib.PASS_C_MFMA_SORTED and plan.lazy_edges and plan.edges_per_thread == 4
-    assert plan.enc_kernel[0] == _lib.GEMM_INLOOP_64 and plan.enc_split_k[1] == 4       # the regime this test is for
+    assert plan.enc_kernel[0] == _lib.GEMM_FEW_L0 and plan.enc_kernel[1] == _lib.GEMM_FEW_WAVE   # the regime this test is for
     got, h = _gpu(m.cuda(), tracker)
     want64, h64 = _oracle(sd, params, tracker)
     assert len(got) == Cs
@@ -172,6 +172,7 @@ def _random_sorted_graph(n, pairs, seed):
 
 THRESHOLDS = [
     # (name, graph below, graph above, plan attribute that must differ)
+    ("1024 node rows", (1000, 30_000), (1100, 30_000), "enc_kernel"),
     ("4096 node rows", (4000, 60_000), (4200, 60_000), "enc_kernel"),
     ("49152 node rows", (49_000, 150_000), (49_300, 150_000), "enc_kernel"),
     ("524288 edges", (3000, 255_000), (3000, 270_000), "edges_per_thread"),

@@ -29,4 +29,4 @@ def test_documented_binding_mirrors_the_header(tmp_path):
     got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     assert got == [ctypes.sizeof(ns["Layer"]), ctypes.sizeof(ns["Model"]), ctypes.sizeof(ns["Call"]),
                    ns["Call"].row_lo.offset, ns["Model"].dropout_enc.offset]
-    assert ns["lib"].mtmc_mpn_abi_version() == 5
+    assert ns["lib"].mtmc_mpn_abi_version() == 6

@@ -55,10 +55,20 @@ def test_row_complete_shard_is_judged_on_its_own_rows(eng):
 
 def test_single_gpu_regimes(eng):
     s02 = eng.plan(450, 150_454)                       # headline graph: few rows, few edges
-    assert s02.enc_kernel == [_lib.GEMM_INLOOP_64] * 4 and s02.enc_split_k[:3] == [4, 4, 4] and s02.enc_split_k[3] == 1
+    # round 5: the few-row kernels (one launch per layer, K never cut across workgroups) where the call has a weight-plane cache
+    assert s02.enc_kernel == [_lib.GEMM_FEW_L0] + [_lib.GEMM_FEW_WAVE] * 3 and s02.enc_split_k == [1, 1, 1, 1]
     assert s02.pass_c == _lib.PASS_C_MFMA_ANY and not s02.lazy_edges and s02.edges_per_thread == 1
+    old = eng.plan(450, 150_454, weight_cache=False)   # ... without one (plain C callers, cache_weight_planes = False): rounds 1-4
+    assert old.enc_kernel == [_lib.GEMM_INLOOP_64] * 4 and old.enc_split_k[:3] == [4, 4, 4] and old.enc_split_k[3] == 1
+    assert old.enc2_passenger
     trk = eng.plan(1002, 751_202)                      # few rows AND more than 524288 edges
-    assert trk.enc_kernel == [_lib.GEMM_INLOOP_64] * 4 and trk.enc_split_k == [1, 4, 4, 1]   # 256 tiles in layer 0: unsplit
+    assert trk.enc_kernel == [_lib.GEMM_FEW_L0] + [_lib.GEMM_FEW_WAVE] * 3
+    trk_old = eng.plan(1002, 751_202, weight_cache=False)
+    assert trk_old.enc_kernel == [_lib.GEMM_INLOOP_64] * 4 and trk_old.enc_split_k == [1, 4, 4, 1]   # 256 tiles in layer 0: unsplit
+    mid = eng.plan(2000, 100_000)                      # more rows than the few-row kernels take, fewer than the many-row ones
+    assert mid.enc_kernel == [_lib.GEMM_INLOOP_64] * 4
+    shard = eng.plan(450, 75_000, 150_454, node_range=(0, 225))    # a rank of a 2-way split of the headline graph
+    assert shard.enc_kernel == s02.enc_kernel
     assert trk.pass_c == _lib.PASS_C_MFMA_SORTED and trk.lazy_edges and trk.edges_per_thread == 4
     cfg4 = eng.plan(100_000, 10_000_000)
     assert cfg4.enc_kernel[0] == _lib.GEMM_PRESPLIT_256 and cfg4.pass_c == _lib.PASS_C_MFMA_SORTED
@@ -76,6 +86,7 @@ def test_single_gpu_regimes(eng):
     assert det_small.pass_c == _lib.PASS_C_WALK         # few edges: fixed-order aggregation lives in the walk
     trn = eng.plan(440, 180_000, training=True)
     assert trn.pass_c == _lib.PASS_C_WALK and not trn.lazy_edges     # Dropout in the node update; e' kept for the tape
+    assert trn.enc_kernel == [_lib.GEMM_INLOOP_64] * 4                # training: the in-loop kernels (no cache, Dropout)
 
 
 def test_deterministic_mode_beyond_the_sorted_kernels_node_limit(eng):
