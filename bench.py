@@ -304,7 +304,35 @@ def cpu_baseline(name, params, sd, data, max_seconds=25.0):
             "host_cpu_count": os.cpu_count()}
 
 
-def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
+def panel_times(model, data, reps=5):
+    """Layer-0 GEMM launches of the ONE-CALL forward (row panels beside the operand split on a side stream), timed by HIP
+    events the library records around each of them on the launch stream (mtmc_dbg_panel_timing): per forward
+    (sum of the panel launches in ms, number of panels), averaged over `reps` forwards.  None on graphs whose layer 0 is not
+    the pre-split kernel."""
+    import ctypes as C
+    lib = _lib.load()
+    fn_on, fn_read = lib.mtmc_dbg_panel_timing, lib.mtmc_dbg_panel_times
+    fn_read.argtypes = [C.POINTER(C.c_float), C.c_int32]
+    if fn_on(1) != 0:
+        return None
+    tot, n_panels = 0.0, 0
+    buf = (C.c_float * 32)()
+    try:
+        with torch.no_grad():
+            for it in range(reps + 1):
+                model(data)
+                n = fn_read(buf, 32)
+                if n == 0:
+                    return None
+                if it > 0:
+                    tot += sum(buf[i] for i in range(n))
+                    n_panels = n
+    finally:
+        fn_on(0)
+    return tot / reps, n_panels
+
+
+def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20, legs=True):
     desc, L, cs = WORKLOADS[name]
     params = mtmc_mpn.default_params(num_enc_steps=L, num_class_steps=cs)
     torch.manual_seed(0)
@@ -315,7 +343,7 @@ def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
     sec, dist_ms = time_forward(model, data, steps, warmup)
     launch_mode, eager_ms, replay_ms = "eager launches", sec * 1e3, None
     if e <= 2_000_000 and not os.environ.get("MTMC_NO_GRAPH"):
-        # few-edge graphs: ~25 launches per forward can cost the host more than the forward costs the GPU; the same
+        # few-edge graphs: ~20 launches per forward can cost the host more than the forward costs the GPU; the same
         # forward replayed from a HIP graph (model.capture) is immune to that -- report the faster way of launching it
         with torch.no_grad():
             replay = model.capture(data)
@@ -326,52 +354,79 @@ def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
     seq, ms = time_phases(model, data, phase_iters)
     spec = model.spec
     # dominant kernel = the kernel NAME with the largest summed time (all its launches in a step, the same
-    # granularity as a rocprofv3 --stats row); phases that launched nothing (un-split combine) are skipped
+    # granularity as a rocprofv3 --stats row); phases that launch nothing (un-split combine) are skipped
     enc_names = encoder_kernels(model, n, e)
     from mtmc_mpn import engine as _engine
     plan = (model._engine or _engine.ForwardEngine(model)).plan(n, e)     # which kernels the library runs for this size
 
     def kernel_of(ph, arg):
-        return enc_names[arg] if ph == _lib.PH_NODE_ENC else PHASE_NAMES[ph]
+        if ph != _lib.PH_NODE_ENC:
+            return PHASE_NAMES[ph]
+        # the few-row later layers are different instantiations per layer (rocprofv3 lists them separately)
+        return enc_names[arg] + (f"[layer {arg}]" if enc_names[arg] == "few_wave_kernel" else "")
+    launched = [(pa, t) for pa, t in zip(seq, ms) if not (pa[0] == _lib.PH_NODE_COMBINE and plan.enc_split_k[pa[1]] <= 1)]
     by_kind = {}
-    for (ph, arg), t in zip(seq, ms):
-        if ph == _lib.PH_NODE_COMBINE and t < 2e-3:
-            continue
+    for (ph, arg), t in launched:
         by_kind.setdefault(kernel_of(ph, arg), []).append(((ph, arg), t))
     dom_key = max(by_kind, key=lambda k: sum(t for _, t in by_kind[k]))
-    launches = by_kind[dom_key]
-    avg_ms = sum(t for _, t in launches) / len(launches)
-    kinds = [phase_cost(ph, arg, spec, n, e) for (ph, arg), _ in launches]
-    bound = kinds[0][0]
-    work = sum(w for _, w in kinds) / len(kinds)
-    peak_note = None
-    if bound == "mfma" and dom_key in ("gemm_bn_f16x3_kernel", "gemm_f16p_m16_kernel", "gemm_staged_kernel", "gemm_rows_kernel",
-                                       "few_l0_kernel", "few_wave_kernel"):
-        achieved, peak, unit = work / (avg_ms * 1e-3) / 1e12, MFMA_BF16_PEAK_TFLOPS / 3.0, "TFLOP/s"
-        peak_note = ("algorithmic fp32 flops (2*M*N*K) against the fp16 dense MFMA peak (= the bf16 one) / 3: the kernel "
-                     "reaches fp32 accuracy with three fp16 products per fp32 product")
-    elif bound == "mfma" and dom_key == "gemm_bn_bf16x6_kernel":
-        achieved, peak, unit = work / (avg_ms * 1e-3) / 1e12, MFMA_BF16_PEAK_TFLOPS / 6.0, "TFLOP/s"
-        peak_note = ("algorithmic fp32 flops (2*M*N*K) against the bf16 dense MFMA peak / 6: the kernel reaches fp32 "
-                     "accuracy with six bf16 products per fp32 product")
-    elif bound == "mfma":
-        achieved, peak, unit = work / (avg_ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
-    else:
-        achieved, peak, unit = work / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
-    roofline = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
-                "traffic": None, "kernel": dom_key, "avg_kernel_ms": avg_ms, "launches_per_step": len(launches),
-                "algorithmic_per_launch": work, "event_pair_floor_ms": empty_event_pair_ms()}
-    if peak_note:
-        roofline["peak_note"] = peak_note
-    roofline["traffic"] = pmc_traffic(name, dom_key, len(launches))
+
+    def roofline_of(key):
+        launches = by_kind[key]
+        avg_ms = sum(t for _, t in launches) / len(launches)
+        kinds = [phase_cost(ph, arg, spec, n, e) for (ph, arg), _ in launches]
+        bound = kinds[0][0]
+        work = sum(w for _, w in kinds) / len(kinds)
+        peak_note = None
+        base = key.split("[")[0]
+        if bound == "mfma" and base in ("gemm_bn_f16x3_kernel", "gemm_f16p_m16_kernel", "gemm_staged_kernel", "gemm_rows_kernel",
+                                        "few_l0_kernel", "few_wave_kernel"):
+            achieved, peak, unit = work / (avg_ms * 1e-3) / 1e12, MFMA_BF16_PEAK_TFLOPS / 3.0, "TFLOP/s"
+            peak_note = ("algorithmic fp32 flops (2*M*N*K) against the fp16 dense MFMA peak (= the bf16 one) / 3: the kernel "
+                         "reaches fp32 accuracy with three fp16 products per fp32 product")
+        elif bound == "mfma" and base == "gemm_bn_bf16x6_kernel":
+            achieved, peak, unit = work / (avg_ms * 1e-3) / 1e12, MFMA_BF16_PEAK_TFLOPS / 6.0, "TFLOP/s"
+            peak_note = ("algorithmic fp32 flops (2*M*N*K) against the bf16 dense MFMA peak / 6: the kernel reaches fp32 "
+                         "accuracy with six bf16 products per fp32 product")
+        elif bound == "mfma":
+            achieved, peak, unit = work / (avg_ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+        else:
+            achieved, peak, unit = work / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+        rl = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
+              "traffic": None, "kernel": key, "avg_kernel_ms": avg_ms, "launches_per_step": len(launches),
+              "algorithmic_per_launch": work, "timed": "HIP events around each launch of the phase-by-phase forward"}
+        if peak_note:
+            rl["peak_note"] = peak_note
+        return rl
+    roofline = roofline_of(dom_key)
+    roofline["event_pair_floor_ms"] = empty_event_pair_ms()
+    if dom_key == "gemm_f16p_m16_kernel" and plan.layer0_panels > 1:
+        # the one-call forward (what ms_per_step times) runs this layer as row panels beside the operand split: report THAT
+        # structure -- the sum of its panel launches -- and keep the phase path's single launch as a second, named figure
+        pt = panel_times(model, data)
+        if pt is not None:
+            per_step_ms, n_panels = pt
+            work_step = roofline["algorithmic_per_launch"]
+            single = {k: roofline[k] for k in ("achieved", "frac", "avg_kernel_ms", "launches_per_step", "timed")}
+            roofline.update({"achieved": work_step / (per_step_ms * 1e-3) / 1e12, "kernel_ms_per_step": per_step_ms,
+                             "avg_kernel_ms": per_step_ms / n_panels, "launches_per_step": n_panels,
+                             "algorithmic_per_launch": work_step / n_panels, "algorithmic_per_step": work_step,
+                             "timed": "HIP events the library records around every panel launch of the ONE-CALL forward "
+                                      "(mtmc_dbg_panel_timing): the structure ms_per_step times; the operand split of the next "
+                                      "panel runs beside each launch on a side stream",
+                             "phase_path_single_launch": single})
+            roofline["frac"] = roofline["achieved"] / roofline["peak"]
+    roofline["traffic"] = pmc_traffic(name, dom_key.split("[")[0], roofline["launches_per_step"])
     if roofline["traffic"] is not None:
         roofline["traffic_note"] = ("HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/%s_%s_pmc_*.txt "
                                     "(separate rocprofv3 --pmc passes; gfx950 half-count correction on reads)"
                                     % (pmc_round(name), name))
+    # the single longest launch, when it is not the kernel with the largest summed time (the few-row layer 0 on the headline graph)
+    longest = max((it for it in launched if it[0][0] != _lib.PH_BEGIN), key=lambda it: it[1])   # (PH_BEGIN = memset + prep_kernel: two operations)
+    longest_key = kernel_of(*longest[0])
     b_fwd = algorithmic_bytes_forward(n, e, L, cs)
     phases = {}
-    for (ph, arg), t in zip(seq, ms):
-        k = kernel_of(ph, arg) + (f"[{arg}]" if ph == _lib.PH_NODE_ENC else "")
+    for (ph, arg), t in launched:
+        k = kernel_of(ph, arg) + (f"[{arg}]" if ph == _lib.PH_NODE_ENC and "[" not in kernel_of(ph, arg) else "")
         phases[k] = phases.get(k, 0.0) + t
     res = {"workload": name, "description": desc, "N": n, "E": e, "L": L, "Cs": cs,
            "value": e / sec, "ms_per_step": sec * 1e3, "edge_rounds_per_s": e * L / sec,
@@ -380,18 +435,45 @@ def run_single(name, device, steps, warmup, with_cpu=True, phase_iters=20):
            "roofline": roofline,
            "forward_algorithmic": {"bytes": b_fwd, "GBps": b_fwd / sec / 1e9, "frac_of_hbm_peak": b_fwd / sec / 1e9 / HBM_PEAK_GBS,
                                    "note": "SURVEY 8(d) reference-formulation bytes / whole-forward time"},
-           "phase_ms_sum": sum(ms), "phase_ms": {k: round(v, 4) for k, v in phases.items()},
+           "phase_ms_sum": sum(t for _, t in launched), "phase_ms": {k: round(v, 4) for k, v in phases.items()},
            "plan": {"encoder_kernels": enc_names, "enc_split_k": plan.enc_split_k, "edges_per_thread": plan.edges_per_thread,
                     "lazy_edges": plan.lazy_edges, "pass_c": ["walk", "mfma_sorted", "mfma_any"][plan.pass_c],
                     "pass_a_col_blocks": plan.pass_a_col_blocks, "layer0_panels": plan.layer0_panels,
                     "enc2_passenger": plan.enc2_passenger, "node_stat_folded": plan.node_stat_folded,
-                    "layer0_pipeline": os.environ.get("MTMC_L0_PIPELINE", "1 (default: row panels, split on a side stream)")}}
+                    "layer0_pipeline": os.environ.get("MTMC_L0_PIPELINE", "1 (default: row panels, split on a side stream)")},
+           # what every timed forward does about the weights: nothing is trusted from one forward to the next
+           "weight_plane_cache": {"enabled": bool(model.cache_weight_planes),
+                                  "validity": "verified on the device in EVERY timed forward: 64-bit fingerprint per 8 weight rows "
+                                              "against the fp32 weights (csrc/split_body.h); no host-side promise"}}
+    if longest_key != dom_key:
+        res["roofline_longest_launch"] = roofline_of(longest_key)
+    if legs:
+        # the same workload WITHOUT the weight-plane cache (every weight-derived operand made again per forward; few-row graphs:
+        # the split-K kernels of rounds 1-4)
+        model.cache_weight_planes = False
+        u_sec, _ = time_forward(model, data, max(5, steps // 2), max(2, warmup // 2))
+        model.cache_weight_planes = True
+        res["ms_per_step_uncached"] = u_sec * 1e3
     if with_cpu:
         sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
         res["cpu_baseline"] = cpu_baseline(name, params, sd, data)
     del data, model
     torch.cuda.empty_cache()
     return res
+
+
+def exact_fp32_leg(name, steps, warmup):
+    """ms_per_step of the same workload with the exact-fp32 MFMA encoder (MTMC_GEMM_FP32=1: v_mfma_f32_32x32x2_f32 instead of
+    the three-product fp16 split).  The switch is read once per process: a child process of this script."""
+    import subprocess
+    env = dict(os.environ, MTMC_GEMM_FP32="1", MTMC_BENCH_CHILD="1")
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", str(steps), "--warmup", str(warmup),
+           "--no-cpu", "--no-stress"]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        return json.loads(r.stdout.strip().splitlines()[-1])["ms_per_step"]
+    except Exception as ex:   # noqa: BLE001  (a diagnostic leg must not take the bench line down)
+        return f"failed: {ex}"
 
 
 def run_graph_build(device, with_cpu=True):
@@ -610,7 +692,8 @@ def main():
     torch.cuda.set_device(device)
     name = "s02" if args.workload == "auto" else args.workload
     probe = hbm_probe(device)
-    res = run_single(name, device, args.steps, args.warmup, with_cpu=not args.no_cpu)
+    child = bool(os.environ.get("MTMC_BENCH_CHILD"))
+    res = run_single(name, device, args.steps, args.warmup, with_cpu=not args.no_cpu, legs=not child)
     add_measured_peak(res, probe)
     line = {"metric": "MPN forward edges/sec (+ achieved roofline fraction of the dominant kernel)",
             "value": res["value"], "unit": "edges/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -620,17 +703,30 @@ def main():
                        "N": res["N"], "E": res["E"], "parallelism": "1 GPU"},
             "roofline": res["roofline"], "cpu_baseline": res.get("cpu_baseline"), "launch": res["launch"],
             "forward_algorithmic": res["forward_algorithmic"], "edge_rounds_per_s": res["edge_rounds_per_s"],
-            "phase_ms": res["phase_ms"], "step_ms": res["step_ms"], "hbm_probe": probe}
+            "phase_ms": res["phase_ms"], "step_ms": res["step_ms"], "hbm_probe": probe, "plan": res["plan"],
+            "weight_plane_cache": res["weight_plane_cache"], "ms_per_step_uncached": res.get("ms_per_step_uncached")}
+    if "roofline_longest_launch" in res:
+        line["roofline_longest_launch"] = res["roofline_longest_launch"]
+    if not child and not args.no_stress:
+        line["ms_per_step_exact_fp32"] = exact_fp32_leg(name, args.steps, args.warmup)
     if args.workload == "auto" and not args.no_stress:
-        st = run_single("cfg4", device, max(5, args.steps // 10), max(2, args.warmup // 10), with_cpu=not args.no_cpu,
+        # (20 timed forwards after 5: with 5 after 2 the first clock ramp of a 2.6 ms forward was part of the figure)
+        st = run_single("cfg4", device, max(20, args.steps // 5), max(5, args.warmup // 4), with_cpu=not args.no_cpu,
                         phase_iters=5)
         add_measured_peak(st, probe)
         line["stress"] = st
         # the multi-GPU workload (config 5) on this one GPU: the N=1 point of the strong-scaling curve
-        line["scale_base"] = run_single("cfg5", device, 5, 2, with_cpu=False, phase_iters=2)
+        line["scale_base"] = run_single("cfg5", device, 6, 3, with_cpu=False, phase_iters=2)
         add_measured_peak(line["scale_base"], probe)
         line["scale_base"]["note"] = ("1-GPU point of the strong-scaling series that `--gpus N` (N > 1) reports: the same "
                                       "1M-node / 100M-edge graph, one call, no collectives")
+        # the two config-2 legs BASELINE.json words: the shipped L = 1 model on the S02 topology, and the tracker-scale graph
+        line["extra"] = {}
+        for leg in ("s02_L1", "s02_tracker"):
+            r = run_single(leg, device, args.steps, args.warmup, with_cpu=False, phase_iters=5)
+            add_measured_peak(r, probe)
+            line["extra"][leg] = {k: r[k] for k in ("description", "N", "E", "L", "Cs", "value", "ms_per_step", "ms_per_step_uncached",
+                                                     "edge_rounds_per_s", "launch", "step_ms", "roofline", "phase_ms", "plan")}
         line["graph_build"] = run_graph_build(device, with_cpu=not args.no_cpu)
         line["training_step"] = run_training_step(device)
         line["postprocess"] = run_postprocess(device, with_cpu=not args.no_cpu)

@@ -29,23 +29,35 @@ Side* side_for_current_device() {
   return &sd;
 }
 
-// The pipelined layer 0's side stream and events, one set per device.
-SidePipe* pipe_for_current_device() {
-  static SidePipe pipes[64];
-  static bool ok[64];
+// The pipelined layer 0's side stream and events: one set per (device, CALLER STREAM).  Round 4 had one per device: two host
+// threads (or two streams) running many-row forwards on one device then recorded and waited on the SAME event objects, and a
+// panel GEMM of one could start on the other's `ready[i]`.  A set whose creation fails half-way is destroyed
+// again; at most kMaxPipes sets exist (beyond that: the serial layer 0).
+constexpr int kMaxPipes = 64;
+struct PipeSlot { int dev; hipStream_t caller; SidePipe pipe; };
+void destroy_pipe(SidePipe& sp, int n_events) {
+  for (int i = 0; i < n_events; ++i) (void)hipEventDestroy(sp.ready[i]);
+  if (sp.fork) (void)hipEventDestroy(sp.fork);
+  if (sp.stream) (void)hipStreamDestroy(sp.stream);
+  sp = SidePipe();
+}
+SidePipe* pipe_for(hipStream_t caller) {
+  static PipeSlot slots[kMaxPipes];
+  static int n_slots = 0;
   static std::mutex mu;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lock(mu);
-  if (!ok[dev]) {
-    SidePipe& sp = pipes[dev];
-    if (hipStreamCreateWithFlags(&sp.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&sp.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-    for (int i = 0; i < kMaxPanels; ++i)
-      if (hipEventCreateWithFlags(&sp.ready[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-    ok[dev] = true;
-  }
-  return &pipes[dev];
+  for (int i = 0; i < n_slots; ++i)
+    if (slots[i].dev == dev && slots[i].caller == caller) return &slots[i].pipe;
+  if (n_slots == kMaxPipes) return nullptr;
+  SidePipe sp = SidePipe();
+  if (hipStreamCreateWithFlags(&sp.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&sp.fork, hipEventDisableTiming) != hipSuccess) { sp.fork = nullptr; destroy_pipe(sp, 0); return nullptr; }
+  for (int i = 0; i < kMaxPanels; ++i)
+    if (hipEventCreateWithFlags(&sp.ready[i], hipEventDisableTiming) != hipSuccess) { destroy_pipe(sp, i); return nullptr; }
+  slots[n_slots] = {dev, caller, sp};
+  return &slots[n_slots++].pipe;
 }
 
 }  // namespace
@@ -83,6 +95,30 @@ int32_t mtmc_mpn_workspace_layout(const mtmc_mpn_model* model, int64_t n_nodes, 
   make_layout(model, n_nodes, n_edges, &lo);
   *out = lo.pub;
   return MTMC_OK;
+}
+
+// Diagnostics: time every layer-0 GEMM launch (row panels) of the many-row forwards that follow with HIP events on the call's
+// stream; mtmc_dbg_panel_times synchronises the LAST forward's events and returns their number (elapsed ms in `ms`).
+int32_t mtmc_dbg_panel_timing(int32_t enable) {
+  PanelTiming& pt = panel_timing();
+  if (enable && !pt.created) {
+    for (int i = 0; i < 2 * kMaxPanels; ++i)
+      if (hipEventCreate(&pt.ev[i]) != hipSuccess) return fail(MTMC_E_HIP, "hipEventCreate failed");
+    pt.created = true;
+  }
+  pt.on = enable != 0;
+  pt.n = 0;
+  return MTMC_OK;
+}
+int32_t mtmc_dbg_panel_times(float* ms, int32_t max) {
+  PanelTiming& pt = panel_timing();
+  if (!ms || !pt.created) return 0;
+  int n = 0;
+  for (; n < pt.n && n < max; ++n) {
+    if (hipEventSynchronize(pt.ev[2 * n + 1]) != hipSuccess) break;
+    if (hipEventElapsedTime(&ms[n], pt.ev[2 * n], pt.ev[2 * n + 1]) != hipSuccess) break;
+  }
+  return n;
 }
 
 int32_t mtmc_mpn_run_phase(const mtmc_mpn_model* model, const mtmc_mpn_call* call, int32_t phase, int32_t arg) {
@@ -174,7 +210,7 @@ int32_t mtmc_mpn_forward(const mtmc_mpn_model* model, const mtmc_mpn_call* call)
   if (mtmc::knobs().l0_pipeline > 0 && use_presplit0(x)) {
     int64_t cuts[kMaxPanels + 1];
     int bm;
-    if (l0_panels(call->node_hi - call->node_lo, model->enc_node[0].out_dim, cuts, &bm) >= 2) x.pipe = pipe_for_current_device();
+    if (l0_panels(call->node_hi - call->node_lo, model->enc_node[0].out_dim, cuts, &bm) >= 2) x.pipe = pipe_for(x.stream);
   }
   Side* sd = (call->flags & MTMC_F_FORK) ? side_for_current_device() : nullptr;
   if (sd) {

@@ -214,7 +214,13 @@ inline void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* l
 
 // Side stream + events of the pipelined layer 0 (api.hip: one set per device, created on first use)
 constexpr int kMaxPanels = 16;
-struct SidePipe { hipStream_t stream; hipEvent_t fork; hipEvent_t ready[kMaxPanels]; };
+struct SidePipe { hipStream_t stream = nullptr; hipEvent_t fork = nullptr; hipEvent_t ready[kMaxPanels] = {}; };
+
+// Diagnostics (bench.py): HIP events around every layer-0 GEMM launch of a many-row forward -- in the pipelined forward the
+// layer is several panel launches beside the operand split on a side stream, and the figure a bench line reports must be
+// that of the forward it sits beside.  Off by default; mtmc_dbg_panel_timing / mtmc_dbg_panel_times (api.hip).
+struct PanelTiming { bool on = false, created = false; hipEvent_t ev[2 * kMaxPanels]; int n = 0; };
+inline PanelTiming& panel_timing() { static PanelTiming t; return t; }
 
 struct Ctx {
   const mtmc_mpn_model* m;
@@ -572,20 +578,32 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
           q.M_rows = rows;
           if (hipEventRecord(x.pipe->fork, s) != hipSuccess || hipStreamWaitEvent(x.pipe->stream, x.pipe->fork, 0) != hipSuccess)
             return fail(MTMC_E_HIP, "encoder layer 0: fork onto the side stream failed");
+          // from here on the side stream is forked off `s` (inside a capture: part of it): every way out joins it again
+          auto join_and = [&](int code, const char* what) {
+            if (hipEventRecord(x.pipe->ready[0], x.pipe->stream) == hipSuccess) (void)hipStreamWaitEvent(s, x.pipe->ready[0], 0);
+            return fail(code, "%s", what);
+          };
           for (int i = 0; i < np; ++i) {
             mtmc::launch_split_rows_range(c->x, c->x_row_stride, rows, Lr.in_dim, x.at<void>(x.lo.xh), x.at<float>(x.lo.inv_a),
                                           cuts[i], cuts[i + 1], x.pipe->stream);
-            if (hipEventRecord(x.pipe->ready[i], x.pipe->stream) != hipSuccess) return fail(MTMC_E_HIP, "hipEventRecord failed");
+            if (hipEventRecord(x.pipe->ready[i], x.pipe->stream) != hipSuccess) return join_and(MTMC_E_HIP, "hipEventRecord failed");
           }
+          PanelTiming& pt = panel_timing();
+          if (pt.on) pt.n = 0;
           for (int i = 0; i < np; ++i) {               // (the wait on the last panel's event also joins the side stream)
-            if (hipStreamWaitEvent(s, x.pipe->ready[i], 0) != hipSuccess) return fail(MTMC_E_HIP, "hipStreamWaitEvent failed");
+            if (hipStreamWaitEvent(s, x.pipe->ready[i], 0) != hipSuccess) return join_and(MTMC_E_HIP, "hipStreamWaitEvent failed");
             q.m_lo = cuts[i]; q.M = cuts[i + 1];
+            if (pt.on) (void)hipEventRecord(pt.ev[2 * i], s);
             const int rc = mtmc::launch_gemm_presplit(q, s);
-            if (rc != 0) return fail(rc == MTMC_E_HIP ? MTMC_E_HIP : MTMC_E_ARG, "encoder layer 0: pre-split GEMM refused a panel");
+            if (pt.on) { (void)hipEventRecord(pt.ev[2 * i + 1], s); pt.n = i + 1; }
+            if (rc != 0) return join_and(rc == MTMC_E_HIP ? MTMC_E_HIP : MTMC_E_ARG, "encoder layer 0: pre-split GEMM refused a panel");
           }
           break;
         }
+        PanelTiming& pt = panel_timing();
+        if (pt.on) { pt.n = 0; (void)hipEventRecord(pt.ev[0], s); }
         const int rc = mtmc::launch_gemm_presplit(q, s);
+        if (pt.on) { (void)hipEventRecord(pt.ev[1], s); pt.n = 1; }
         if (rc != 0) return fail(rc == MTMC_E_HIP ? MTMC_E_HIP : MTMC_E_ARG, "encoder layer 0: pre-split GEMM refused the shape or the launch");
         break;
       }

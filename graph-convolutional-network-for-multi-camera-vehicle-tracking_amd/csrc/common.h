@@ -163,18 +163,48 @@ __device__ __forceinline__ void stat_gather2(const double* srcA, int nA, int str
   }
 }
 
+// Wave totals of NV per-lane doubles, written to out[0 .. NV) by the lanes that end up holding them.  Round 5: the block
+// epilogues of the few-edge passes were 2100-3400 cycles (profiles/r05_edge_stamps.txt), most of it one six-step DPP sum per
+// value (two v_mov_dpp + one v_add_f64 per step: 18 instructions per value, 252 for pass B's 14).  Here pairs of values are
+// folded across the wave's halves (v_permlane32_swap on both dwords + one add leaves value 2i in lanes 0-31 and 2i+1 in
+// lanes 32-63), pairs of those across the 16-lane rows (v_permlane16_swap), and only the last four steps run inside a row:
+// 3 + 1.5 + 12 / 4 = 5.25 instructions per value instead of 18.  Same additions in a different association: fp64.
+__device__ __forceinline__ double swap_add_f64_32(double a, double b) {     // lanes 0-31: a[l] + a[l+32]; lanes 32-63: b[l-32] + b[l]
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double swap_add_f64_16(double a, double b) {     // rows 0 / 2: a's pair of rows, rows 1 / 3: b's
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+template <int NV>
+__device__ __forceinline__ void wave_sums_f64(const double (&v)[NV], double* out) {
+  constexpr int N4 = (NV + 3) / 4;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int q = 0; q < N4; ++q) {
+    const double v0 = v[4 * q], v1 = 4 * q + 1 < NV ? v[4 * q + 1] : 0.0, v2 = 4 * q + 2 < NV ? v[4 * q + 2] : 0.0,
+                 v3 = 4 * q + 3 < NV ? v[4 * q + 3] : 0.0;
+    double u = swap_add_f64_16(swap_add_f64_32(v0, v1), swap_add_f64_32(v2, v3));   // rows 0..3: values 0, 2, 1, 3 of the quad
+    u = dpp_add_f64<0x111, 0xf>(u);   // row_shr:1
+    u = dpp_add_f64<0x112, 0xf>(u);   // row_shr:2
+    u = dpp_add_f64<0x114, 0xf>(u);   // row_shr:4
+    u = dpp_add_f64<0x118, 0xf>(u);   // row_shr:8: the row's last lane holds its total
+    const int idx = 4 * q + wave_sum4_slot(lane);
+    if ((lane & 15) == 15 && idx < NV) out[idx] = u;
+  }
+}
+
 // Block-wide sum of NV per-thread doubles; result atomically added to this block's replica of dst.
 // smem: at least NV * (blockDim.x/64) doubles.  All threads must call.
 template <int NV>
 __device__ __forceinline__ void block_atomic_add(const double (&v)[NV], double* dst_base, int stride, double* smem,
                                                  int block = -1) {   // block: replica chooser (default: blockIdx.x)
   double* dst = dst_base + ((block < 0 ? (int)blockIdx.x : block) % kStatRep) * stride;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    double s = wave_sum(v[i]);
-    if (lane == kWaveSumLane) smem[wid * NV + i] = s;
-  }
+  const int wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  wave_sums_f64<NV>(v, smem + wid * NV);
   __syncthreads();
   for (int i = threadIdx.x; i < NV; i += blockDim.x) {
     double s = 0;
@@ -199,6 +229,23 @@ __device__ __forceinline__ void bn_affine(double sum, double sumsq, double count
   s = (float)sd;
   t = (float)fma(-mean, sd, (double)beta);
 }
+
+// In-kernel stamps of the few-edge round kernels (-DEK_STAMP=1, tools/edge_stamps.py; tools/build_variant.sh): s_memtime at up to
+// eight points of workgroup 0 and of the workgroup in the middle of the grid, thread 0.  One buffer per translation unit.
+#ifndef EK_STAMP
+#define EK_STAMP 0
+#endif
+#if EK_STAMP
+constexpr int kEkKernels = 8, kEkPoints = 8;
+static __device__ unsigned long long g_ek[kEkKernels * 2 * kEkPoints];
+#define EK_T(kid, pt)                                                                                          \
+  do {                                                                                                         \
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2))                                  \
+      g_ek[((kid) * 2 + (blockIdx.x != 0)) * kEkPoints + (pt)] = __builtin_amdgcn_s_memtime();                 \
+  } while (0)
+#else
+#define EK_T(kid, pt) do {} while (0)
+#endif
 
 // Dropout (training mode only; reference models/mlp.py:21-22): counter-based, so any kernel -- forward or
 // backward, or the CPU model in tests/ -- regenerates the same mask from (seed, stream, element index).

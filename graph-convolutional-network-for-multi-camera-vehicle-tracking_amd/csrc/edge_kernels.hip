@@ -59,17 +59,21 @@ __device__ void amax_jobs(const PrepParams& p, int block) {
 }
 
 __global__ __launch_bounds__(256) void prep_kernel(PrepParams p) {
-  if ((int)blockIdx.x >= p.n_edge_blocks) {             // passenger workgroups: operand scales of the node encoder
-    amax_jobs(p, blockIdx.x - p.n_edge_blocks);
+  // passenger workgroups (operand scales / operand splits of the node encoder, the weight-plane cache's verification) come
+  // FIRST in the grid: they are the longest (64 KB of reads each) and nothing else of the forward can start before the last
+  // of them is done
+  if ((int)blockIdx.x < p.n_pass_blocks) {
+    amax_jobs(p, blockIdx.x);
     return;
   }
+  const int eb = (int)blockIdx.x - p.n_pass_blocks;     // this workgroup's index among the edge workgroups
   __shared__ double red[5 * 4];
   double acc[5] = {0, 0, 0, 0, 0};
   const int lane = threadIdx.x & 63;
   const int64_t nthreads = (int64_t)p.n_edge_blocks * blockDim.x;
   // whole waves iterate together so that the run-length logic sees 64 consecutive edges
   const int64_t e_end = ((p.n_edges + 63) / 64) * 64;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < e_end; e += nthreads) {
+  for (int64_t e = (int64_t)eb * blockDim.x + threadIdx.x; e < e_end; e += nthreads) {
     const bool active = e < p.n_edges;
     int64_t r64 = 0, c64 = 0;
     if (active) {
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepParams p) {
       atomicAdd(p.deg + r, len);
     }
   }
-  block_atomic_add<5>(acc, p.stat_attr, kAttrStride, red);
+  block_atomic_add<5>(acc, p.stat_attr, kAttrStride, red, eb);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -294,6 +298,7 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 5 : 1)) void pass_a_kernel(RoundP
   EdgeConstsS ks;                                  // first thing in the kernel: ahead of every store and barrier these
   load_edge_consts_s<MODE>(p, ks);                 // uniform loads are scalar loads (SGPRs); behind one they become vector loads
   if (p.col_blocks > 0 && p.flags[0] == 0 && p.flags[2] == 0) return;   // pass_a_blocked_kernel, launched just before, did this round
+  EK_T(MODE == 0 ? 1 : 2, 0);
   if (p.lazy_e && !(MODE & 1)) {
     stat_gather(p.prev_stats + kRoundZ1Off, 8, kZ1Stride, red);
     __syncthreads();
@@ -302,6 +307,7 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 5 : 1)) void pass_a_kernel(RoundP
                 pa_s.s[threadIdx.x], pa_s.t[threadIdx.x]);
   }
   stage_edge_consts<MODE>(p, &cs_s);               // (barrier inside: pa_s is visible too)
+  EK_T(MODE == 0 ? 1 : 2, 1);
   PrevAffine pa;
 #pragma unroll
   for (int j = 0; j < 4; ++j) { pa.s[j] = pa_s.s[j]; pa.t[j] = pa_s.t[j]; }
@@ -351,7 +357,9 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 5 : 1)) void pass_a_kernel(RoundP
       finish(e, in);
     }
   }
+  EK_T(MODE == 0 ? 1 : 2, 2);
   block_atomic_add<8>(acc, p.stats + kRoundZ1Off, kZ1Stride, red);
+  EK_T(MODE == 0 ? 1 : 2, 3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -605,15 +613,18 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
       }
     }
   };
+  EK_T(3, 0);
   if (base < e_end) fetch(base);
   stat_gather(p.stats + kRoundZ1Off, 8, kZ1Stride, red);
   if (base < e_end) prefetch_q();
   __syncthreads();
+  EK_T(3, 1);
   if (threadIdx.x < 4) {
     const int k = threadIdx.x;
     bn_affine(red[k], red[4 + k], p.e_total, p.ue_g[k], p.ue_bt[k], s1[k], t1[k]);
   }
   __syncthreads();
+  EK_T(3, 2);
   double acc[14];
 #pragma unroll
   for (int i = 0; i < 14; ++i) acc[i] = 0;
@@ -725,17 +736,14 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
     base += stride;
     if (base < e_end) fetch(base);
   }
+  EK_T(3, 3);
   // ---- the block's sums: moments of e' -> the M block; A_k . m1 and 2 A_k . C[:,k] -> the node-update (z2) block
   {
     const int wid = threadIdx.x >> 6;
     double* sm_m = red;                  // [4 waves][14]
     double* sm_c = red + 14 * 4;         // [4 waves][128]: C[j][k] at j * 32 + k
     double* sm_m1 = sm_c + 4 * 128;      // [4]
-#pragma unroll
-    for (int i = 0; i < 14; ++i) {
-      const double sacc = wave_sum(acc[i]);
-      if (lane == kWaveSumLane) sm_m[wid * 14 + i] = sacc;
-    }
+    wave_sums_f64<14>(acc, sm_m + wid * 14);            // (common.h: pairs folded by permlane swaps, 5 instructions per value)
     sm_c[wid * 128 + (2 * hh) * 32 + k32] = c0;
     sm_c[wid * 128 + (2 * hh + 1) * 32 + k32] = c1;
     __syncthreads();
@@ -764,6 +772,7 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
       unsafeAtomicAdd(z_dst + 32 + k, 2.0 * cross);
     }
   }
+  EK_T(3, 4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -942,11 +951,13 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: spans, chunks, rows stay scalar
   const int k = lane & 31, hi = lane >> 5;
   if (p.mfma_c == 1 && p.flags[0] != 0) return;              // unsorted rows: pass_c_kernel does this round (block-uniform)
+  EK_T(4, 0);
   stat_gather2(p.stats + kRoundMOff + 4, 10, kMStride, p.stats + kRoundZ2Off, 64, kZ2Stride, st);
   __shared__ double st1[8];
   __shared__ float s1s[4], t1s[4];
   if (p.lazy_e) stat_gather(p.stats + kRoundZ1Off, 8, kZ1Stride, st1);
   __syncthreads();
+  EK_T(4, 1);
   float s1[4] = {1.f, 1.f, 1.f, 1.f}, t1[4] = {0.f, 0.f, 0.f, 0.f};
   if (p.lazy_e) {                                            // the edge buffer holds z1: e' = relu(s1 z1 + t1), recomputed here
     if (threadIdx.x < 4)
@@ -974,6 +985,7 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
       for (int j = 0; j < 4; ++j) cw[c][j] = p.cls_w[c * 4 + j];
     }
 
+  EK_T(4, 2);
   const int64_t n_chunks = (p.n_edges + 63) / 64;
   const int64_t n_spans = (n_chunks + span_c - 1) / span_c;
   const int64_t wave_stride = (int64_t)gridDim.x * 4;
@@ -1033,20 +1045,29 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
     const int64_t c0_chunk = span * span_c;
     float4 ev_1, ev_2;
     int rw_1, rw_2;
+    // (requesting the wave's first chunk BEFORE the statistics are gathered -- it does not depend on them -- was measured in
+    //  round 5 and took 1.6 us MORE per launch on the 150k-edge graph, profiles/r05_s02_edge_trims.txt: not kept)
     fetch(c0_chunk, ev_1, rw_1);
     rows_of(rw_1, c0_chunk, qa_row, qb_row);
     qa = p.Q[(int64_t)qa_row * kH + k];
     qb = p.Q[(int64_t)qb_row * kH + k];
-    fetch(c0_chunk + 1, ev_2, rw_2);
+    // Nothing is requested for chunks past the span's end: on few-edge lists a span is ONE chunk, and waiting for the row ids
+    // of a next chunk that does not exist was a whole round trip in front of the only chunk's MFMAs (round 5 stamps,
+    // profiles/r05_edge_stamps.txt: 7.0 -> 5.7 us per launch)
+    ev_2 = ev_1; rw_2 = rw_1;
+    if (c0_chunk + 1 < c_end) fetch(c0_chunk + 1, ev_2, rw_2);
     for (int64_t chunk = c0_chunk; chunk < c_end; ++chunk) {
       // ---- chunk + 1: its row ids were requested one iteration ago; request its Q rows.  chunk + 2: request the stream.
-      int qa_row_2, qb_row_2;
-      rows_of(rw_2, chunk + 1, qa_row_2, qb_row_2);
-      const float qa_2 = p.Q[(int64_t)qa_row_2 * kH + k];
-      const float qb_2 = p.Q[(int64_t)qb_row_2 * kH + k];
-      float4 ev_3;
-      int rw_3;
-      fetch(chunk + 2, ev_3, rw_3);
+      int qa_row_2 = qa_row, qb_row_2 = qb_row;
+      float qa_2 = qa, qb_2 = qb;
+      if (chunk + 1 < c_end) {
+        rows_of(rw_2, chunk + 1, qa_row_2, qb_row_2);
+        qa_2 = p.Q[(int64_t)qa_row_2 * kH + k];
+        qb_2 = p.Q[(int64_t)qb_row_2 * kH + k];
+      }
+      float4 ev_3 = ev_2;
+      int rw_3 = rw_2;
+      if (chunk + 2 < c_end) fetch(chunk + 2, ev_3, rw_3);
       // ---- chunk: all in registers
       const int64_t e = chunk * 64 + lane;
       const bool valid = e < p.n_edges;
@@ -1205,6 +1226,7 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
     }
     flush();
   }
+  EK_T(4, 3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1556,6 +1578,7 @@ void launch_prep(const PrepParams& p0, hipStream_t s) {
                                                      : (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
     extra += p.jobs[j].n_blocks;
   }
+  p.n_pass_blocks = extra;
   if (p.n_edge_blocks + extra == 0) return;
   hipLaunchKernelGGL(prep_kernel, dim3(p.n_edge_blocks + extra), dim3(256), 0, s, p);
 }
@@ -1690,7 +1713,16 @@ void launch_pass_c(const RoundParams& p0, hipStream_t s) {
     const int cap = max_blocks < 256 * 3 ? max_blocks : 256 * 3;           // 130 registers: three blocks per CU
     hipLaunchKernelGGL(pass_c_mfma_kernel, dim3((int)(blocks > cap ? cap : blocks)), dim3(256), 0, s, p, span_c);
   }
-  if (p.mfma_c != 2) hipLaunchKernelGGL(pass_c_kernel, dim3(edge_grid(p.n_edges, kTileC)), dim3(kTileC), 0, s, p);
+  if (p.mfma_c != 2) {
+    // Behind a matrix-core kernel the walk only does the < 64 edges behind a sorted list's last whole chunk (one workgroup) --
+    // or, when prep_kernel found the rows unsorted (known on the device only: the launch cannot be skipped from the host), the
+    // whole round.  Rounds 3-4 launched the full grid of up to 2048 workgroups, 5 us of dispatch per round that only returned
+    // on every sorted list; now one workgroup per CU (grid-stride loop): 1/8 of the dispatch, and an UNSORTED many-edge list
+    // -- the exception: the reference's lists are row-sorted -- walks with 256 workgroups instead of 2048.
+    const int full = edge_grid(p.n_edges, kTileC);
+    const int grid = (p.mfma_c == 0) ? full : (full < 256 ? full : 256);
+    hipLaunchKernelGGL(pass_c_kernel, dim3(grid), dim3(kTileC), 0, s, p);
+  }
   if (p.det && p.agg != 2) {
     const int64_t blocks = (p.n_nodes + 7) / 8;
     hipLaunchKernelGGL(agg_fixup_kernel, dim3((int)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks))), dim3(256), 0, s, p);
@@ -1703,3 +1735,9 @@ void launch_classify_e0(const EdgeEncParams& enc, const float* attr, int64_t n_e
 }
 
 }  // namespace mtmc
+
+#if EK_STAMP
+extern "C" int mtmc_dbg_ek_stamps_edge(unsigned long long* out) {    // host buffer of 8 * 2 * 8 entries
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mtmc::g_ek), sizeof(mtmc::g_ek));
+}
+#endif

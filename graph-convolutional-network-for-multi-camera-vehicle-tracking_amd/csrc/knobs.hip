@@ -28,7 +28,8 @@ static Knobs read_knobs() {
   k.no_col_blocks = on("MTMC_NO_COL_BLOCKS");
   k.col_blocks = (int)num("MTMC_COL_BLOCKS", 0);
   k.gemm_no_few = on("MTMC_GEMM_NO_FEW");
-  k.few_rows_max = (int)num("MTMC_FEW_ROWS_MAX", 1024);
+  k.few_rows_max = (int)num("MTMC_FEW_ROWS_MAX", 1536);    // measured crossover: tools/few_crossover.py, profiles/r05_few_crossover.txt
+  k.few_wave_rb = (int)num("MTMC_FEW_WAVE_RB", 0);
   return k;
 }
 

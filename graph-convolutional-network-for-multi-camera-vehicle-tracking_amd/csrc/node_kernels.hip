@@ -14,8 +14,8 @@
 namespace mtmc {
 
 #ifndef MTMC_PROJ_MFMA_MIN
-#define MTMC_PROJ_MFMA_MIN 4096
-#endif
+#define MTMC_PROJ_MFMA_MIN 1     // (rounds 3-4: 4096 -- few-node graphs kept the LDS kernel, "both at the launch floor"; stamped in
+#endif                           //  round 5, the LDS kernel is 4.2 us of dependent round trips per workgroup, this one 2: DESIGN.md 5)
 constexpr int64_t kProjMfmaMinRows = MTMC_PROJ_MFMA_MIN;   // node rows from which the matrix-core projection kernel is used
 constexpr int kProjNodes = 16;   // nodes per block iteration (16 lanes per node: 8 output groups x 2 halves of the k range)
 constexpr int kProjOut = 40;     // 4 (Pr) + 4 (Pc) + 32 (Q)
@@ -29,6 +29,7 @@ __global__ __launch_bounds__(256) void node_proj_kernel(NodeProjParams p) {
   __shared__ double zred[4][2 * kH];               // node-only part of the z2 statistics per wave: sum deg qb | sum deg qb^2
   double zs1[4] = {0, 0, 0, 0}, zs2[4] = {0, 0, 0, 0};
   const int hn = p.hn, ldh = hn + 2;
+  EK_T(0, 0);
   for (int i = threadIdx.x; i < hn * kProjOut; i += blockDim.x) {
     const int kk = i / kProjOut, j = i % kProjOut;
     float w;
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(256) void node_proj_kernel(NodeProjParams p) {
     // (the node's out-degree: requested here, used after the projections)
     const double dnode = (p.z2_stats && node0 + nl < p.node_end) ? (double)p.edge_deg[node0 + nl] : 0.0;
     __syncthreads();                               // wt/ys ready / previous hs consumed
+    EK_T(0, 1);
     // stage the h rows of 32 nodes (1024 floats), then mirror / fetch the h0 half when reattaching
     for (int i = threadIdx.x; i < kProjNodes * kH; i += blockDim.x) {
       const int n = i >> 5, kk = i & 31;
@@ -76,6 +78,7 @@ __global__ __launch_bounds__(256) void node_proj_kernel(NodeProjParams p) {
         reinterpret_cast<float4*>(p.zero_buf + node * kH)[threadIdx.x & 7] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
+    EK_T(0, 2);
     float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     // a lane pair takes the even / the odd k: with row stride hn+2 the eight (node, k) words and the sixteen weights a
     // wave reads per step sit on different banks (halves of the k range, 32 apart, met on the same banks: 42 % of this
@@ -102,6 +105,7 @@ __global__ __launch_bounds__(256) void node_proj_kernel(NodeProjParams p) {
       }
     }
   }
+  EK_T(0, 3);
   if (p.z2_stats) {        // a wave holds 4 node lanes (bits 4, 5 of the lane id) x 16: fold them, then the 4 waves through LDS
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -121,10 +125,12 @@ __global__ __launch_bounds__(256) void node_proj_kernel(NodeProjParams p) {
       unsafeAtomicAdd(p.z2_stats + (blockIdx.x % kStatRep) * kZ2Stride + threadIdx.x,
                       zred[0][threadIdx.x] + zred[1][threadIdx.x] + zred[2][threadIdx.x] + zred[3][threadIdx.x]);
   }
+  EK_T(0, 4);
   if (p.finalize_enc && blockIdx.x == 0) {         // once per forward: the edge encoder's two BatchNorm affines
     edge_enc_affine_to_smem(p.enc, p.e_total, 2, &enc_af, scratch);
     if (threadIdx.x < 16) p.enc.aff[threadIdx.x] = reinterpret_cast<const float*>(&enc_af)[threadIdx.x];
   }
+  EK_T(0, 5);
 }
 
 // The same projections on the matrix cores, one wave per 16 nodes, no LDS and no barriers: [16 nodes][hn] . [hn][40 -> 48]
@@ -146,13 +152,10 @@ __global__ __launch_bounds__(256) void node_proj_mfma_kernel(NodeProjParams p) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int i16 = lane & 15, g = lane >> 4;
   const float ub0 = p.z2_stats ? p.un_b[i16] : 0.f, ub1 = p.z2_stats ? p.un_b[16 + i16] : 0.f;
-  if (p.y_last) {
-    if (threadIdx.x < kH)
-      bn_affine(p.y_stats[threadIdx.x], p.y_stats[kH + threadIdx.x], p.y_count, p.y_gamma[threadIdx.x],
-                p.y_beta[threadIdx.x], ys[threadIdx.x], yt[threadIdx.x]);
-    __syncthreads();
-  }
-  // B fragments: bw[nb][half][s] = W_out[n = 16 nb + i16][k = 32 half + 8 g + s]
+  EK_T(5, 0);
+  // B fragments: bw[nb][half][s] = W_out[n = 16 nb + i16][k = 32 half + 8 g + s].  Requested FIRST: the (fused round 0)
+  // BatchNorm statistics of the encoder's last layer, their barrier and the first group's rows then travel beside them
+  // instead of behind them (few-node graphs: the kernel is three dependent round trips otherwise)
   float bw[3][HALVES][8];
 #pragma unroll
   for (int nb = 0; nb < 3; ++nb)
@@ -167,16 +170,32 @@ __global__ __launch_bounds__(256) void node_proj_mfma_kernel(NodeProjParams p) {
         else if (i16 < 8) w = p.ue_w[(i16 - 4) * p.ue_ld + p.hn + kk];
         bw[nb][hf][s8] = w;
       }
+  if (p.y_last) {
+    if (threadIdx.x < kH)
+      bn_affine(p.y_stats[threadIdx.x], p.y_stats[kH + threadIdx.x], p.y_count, p.y_gamma[threadIdx.x],
+                p.y_beta[threadIdx.x], ys[threadIdx.x], yt[threadIdx.x]);
+    __syncthreads();
+  }
   float ysv[8], ytv[8];
   if (p.y_last) {
 #pragma unroll
     for (int s8 = 0; s8 < 8; ++s8) { ysv[s8] = ys[8 * g + s8]; ytv[s8] = yt[8 * g + s8]; }
   }
+  EK_T(5, 1);
   const int64_t n_groups = (p.node_end - p.node_begin + 15) / 16;
   for (int64_t grp = (int64_t)blockIdx.x * 4 + wid; grp < n_groups; grp += (int64_t)gridDim.x * 4) {
     const int64_t node = p.node_begin + grp * 16 + i16;
     const bool live = node < p.node_end;
     const int64_t nd = live ? node : p.node_end - 1;
+    // (the out-degrees of this lane's four OUTPUT rows: requested with the rows, used behind the MFMAs)
+    double dg[4] = {0, 0, 0, 0};
+    if (p.z2_stats) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t on = p.node_begin + grp * 16 + 4 * g + r;
+        dg[r] = (double)p.edge_deg[on < p.node_end ? on : p.node_end - 1];
+      }
+    }
     float a[HALVES][8];
     {   // the h half (the LAST 32 inputs when reattaching)
       const float* src = (p.y_last ? p.y_last : p.h_src) + nd * kH + 8 * g;
@@ -233,7 +252,7 @@ __global__ __launch_bounds__(256) void node_proj_mfma_kernel(NodeProjParams p) {
         p.Q[on * kH + 16 + i16] = acc[1][r];
         if (i16 < 8) p.P[(i16 < 4 ? on : p.n_nodes + on) * 4 + (i16 & 3)] = acc[2][r];
         if (p.z2_stats) {
-          const double d = (double)p.edge_deg[on];
+          const double d = dg[r];
           const double q0 = (double)(acc[0][r] + ub0), q1 = (double)(acc[1][r] + ub1);
           zs1[0] += d * q0; zs2[0] += d * q0 * q0;
           zs1[1] += d * q1; zs2[1] += d * q1 * q1;
@@ -241,6 +260,7 @@ __global__ __launch_bounds__(256) void node_proj_mfma_kernel(NodeProjParams p) {
       }
     }
   }
+  EK_T(5, 2);
   if (p.z2_stats) {                                // fold the four row groups of a wave, then the waves through LDS
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -259,11 +279,13 @@ __global__ __launch_bounds__(256) void node_proj_mfma_kernel(NodeProjParams p) {
       unsafeAtomicAdd(p.z2_stats + (blockIdx.x % kStatRep) * kZ2Stride + threadIdx.x,
                       zred[0][threadIdx.x] + zred[1][threadIdx.x] + zred[2][threadIdx.x] + zred[3][threadIdx.x]);
   }
+  EK_T(5, 3);
   if (p.finalize_enc && blockIdx.x == 0) {         // once per forward: the edge encoder's two BatchNorm affines
     __syncthreads();
     edge_enc_affine_to_smem(p.enc, p.e_total, 2, &enc_af, scratch);
     if (threadIdx.x < 16) p.enc.aff[threadIdx.x] = reinterpret_cast<const float*>(&enc_af)[threadIdx.x];
   }
+  EK_T(5, 4);
 }
 
 __global__ __launch_bounds__(256) void node_stat_kernel(NodeStatParams p) {
@@ -371,3 +393,9 @@ void launch_h_final(const float* src, const int* deg, int mean, int64_t n_nodes,
 }
 
 }  // namespace mtmc
+
+#if EK_STAMP
+extern "C" int mtmc_dbg_ek_stamps_node(unsigned long long* out) {    // host buffer of 8 * 2 * 8 entries
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mtmc::g_ek), sizeof(mtmc::g_ek));
+}
+#endif

@@ -238,15 +238,26 @@ class _MpForwardLean(torch.autograd.Function):
         prep = _forward_prep(x, edge_index, edge_attr, params, config, training, seed, flags, True)
         ctx.config, ctx.training, ctx.seed, ctx.flags = config, training, seed, flags
         ctx.need_x, ctx.need_attr = x.requires_grad, edge_attr.requires_grad
-        ctx.prep = prep                      # the call structs + the workspace (= tape): the backward runs on the very same call
-        ctx.save_for_backward(x, edge_index, edge_attr, *params)
+        # What the backward needs and NOTHING that refers to the outputs: round 4 kept `prep` itself here, whose logits / h are
+        # this node's outputs -- a reference cycle through C++ (outputs -> grad_fn -> ctx -> prep -> outputs) that only Python's
+        # generational GC could break, so several steps' tapes stayed resident.  The call structs hold raw
+        # pointers only; the tape and the tensors those pointers name (prepare() may have made contiguous copies) are SAVED
+        # tensors: released by autograd when the backward has run (kept under retain_graph), like any other saved activation.
+        ctx.structs = (prep.model, prep.call, prep.n, prep.e, prep.dev)
+        ctx.n_keep = len(prep.keep)
+        ctx.save_for_backward(prep.ws, *prep.keep, *params)
         return prep.logits, prep.h
 
     @staticmethod
     def backward(ctx, d_logits, d_h):
-        x, edge_index, edge_attr, *params = ctx.saved_tensors
-        flat, dx, dattr = _mp_backward(ctx.prep.ws, x, edge_index, edge_attr, params, ctx.config, ctx.training, ctx.seed, ctx.flags,
-                                       d_logits, d_h, ctx.need_x, ctx.need_attr, prep=ctx.prep)
+        import types
+        ws, *rest = ctx.saved_tensors
+        keep, params = rest[:ctx.n_keep], rest[ctx.n_keep:]
+        model, call, n, e, dev = ctx.structs
+        prep = types.SimpleNamespace(model=model, call=call, ws=ws, n=n, e=e, dev=dev, keep=tuple(keep))
+        x, edge_index, edge_attr = keep[0], keep[1], keep[2]
+        flat, dx, dattr = _mp_backward(ws, x, edge_index, edge_attr, params, ctx.config, ctx.training, ctx.seed, ctx.flags,
+                                       d_logits, d_h, ctx.need_x, ctx.need_attr, prep=prep)
         spec = engine_for(ctx.config).spec
         layout, _ = grad_layout(spec)
         grads = [flat[o:o + n].view(shp) for o, n, shp in layout]

@@ -117,6 +117,10 @@ def _skewed_graph(N, E, seed):
     (dict(num_enc_steps=2, num_class_steps=1, reattach_initial_edges=True, reattach_initial_nodes=True), False),
     (dict(num_enc_steps=2, num_class_steps=1), True),       # columns shuffled inside the rows: the in-order kernel must take over
     (dict(num_enc_steps=2, num_class_steps=1), "skewed"),   # empty rows, huge rows, empty sub-runs
+    # the blocked path's correctness hangs on prep_kernel's flags[2] (columns ascending inside a row) and on the
+    # sub-run boundaries snapped to multiples of four edges
+    (dict(num_enc_steps=1, num_class_steps=1), "descending"),      # every row's columns in DESCENDING order: flag -> in-order kernel
+    (dict(num_enc_steps=2, num_class_steps=1), "boundary_dups"),   # many equal columns exactly on the column-block boundaries
 ])
 def test_column_blocked_pass_a_regime(over, unsort_cols):
     """Pass A by column blocks (csrc/edge_kernels.hip pass_a_blocked_kernel: graphs whose Pc table, 16 B per node, outgrows
@@ -130,6 +134,19 @@ def test_column_blocked_pass_a_regime(over, unsort_cols):
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     N, E = 230_000, 9_200_000
     d = _skewed_graph(N, E, 12) if unsort_cols == "skewed" else graphs.stress_graph(N, E // 2, seed=11, device="cuda")
+    if unsort_cols == "descending":
+        key = d.edge_index[0] * N + (N - 1 - d.edge_index[1])
+        perm = torch.argsort(key, stable=True)
+        d.edge_index, d.edge_attr = d.edge_index[:, perm].contiguous(), d.edge_attr[perm].contiguous()
+        same_row = d.edge_index[0][1:] == d.edge_index[0][:-1]
+        assert (d.edge_index[1][1:][same_row] <= d.edge_index[1][:-1][same_row]).all()
+    if unsort_cols == "boundary_dups":
+        wb = N // 8                                           # width of a column block (plan_col_blocks: 8 blocks)
+        side = torch.randint(0, 2, (E,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+        col = (d.edge_index[1] // wb).clamp(max=7) * wb + side * (wb - 1)        # first or last column of its block: runs of equal columns
+        key, perm = torch.sort(d.edge_index[0] * N + col, stable=True)
+        d.edge_index = torch.stack([key // N, key % N]).contiguous()
+        d.edge_attr = d.edge_attr[perm].contiguous()
     plan = engine.ForwardEngine(m).plan(N, E)
     assert plan.pass_a_col_blocks == 8 and plan.pass_c == _lib.PASS_C_MFMA_SORTED
     if unsort_cols is True:                                  # same rows, columns of each row in random order

@@ -172,7 +172,7 @@ def _random_sorted_graph(n, pairs, seed):
 
 THRESHOLDS = [
     # (name, graph below, graph above, plan attribute that must differ)
-    ("1024 node rows", (1000, 30_000), (1100, 30_000), "enc_kernel"),
+    ("1536 node rows", (1500, 30_000), (1600, 30_000), "enc_kernel"),
     ("4096 node rows", (4000, 60_000), (4200, 60_000), "enc_kernel"),
     ("49152 node rows", (49_000, 150_000), (49_300, 150_000), "enc_kernel"),
     ("524288 edges", (3000, 255_000), (3000, 270_000), "edges_per_thread"),
@@ -314,3 +314,37 @@ def test_sorted_many_edge_list_with_low_degree_stretches(tail):
     _check(got, h, want64, h64, f"mixed degrees, E={E} (E % 64 = {tail})")
     deg = torch.bincount(d.edge_index[0], minlength=d.x.shape[0])
     assert int((deg == 0).sum()) > 0 and int(((deg > 0) & (deg < 8)).sum()) > 1000     # the stretches the test is about
+
+
+def test_two_host_threads_run_many_row_forwards_on_their_own_streams():
+    """the pipelined layer 0 had ONE side stream + event set per device; two host threads recorded and waited
+    on the same event objects and a panel GEMM of one could start before its own operand split had finished.  Now one set
+    per (device, caller stream): two threads, two streams, different inputs, interleaved -- each must get its own answer."""
+    import threading
+    m, sd, params = _model(1, 1)
+    m = m.cuda()
+    n = 40_000                                            # two row panels (1 + 2 rounds of workgroups)
+    graphs_ = [_random_sorted_graph(n, 30_000, seed=70 + i) for i in range(2)]
+    data = [types.SimpleNamespace(x=g.x.cuda(), edge_index=g.edge_index.cuda(), edge_attr=g.edge_attr.cuda()) for g in graphs_]
+    assert engine.ForwardEngine(m).plan(n, data[0].edge_index.shape[1]).layer0_panels > 1
+    with torch.no_grad():
+        want = [m(d)[0]["classified_edges"][-1].clone() for d in data]
+    torch.cuda.synchronize()
+    got, errs = [None, None], []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st), torch.no_grad():
+                for _ in range(12):
+                    out = m(data[i])[0]["classified_edges"][-1]
+                st.synchronize()
+            got[i] = out
+        except Exception as ex:   # noqa: BLE001
+            errs.append(ex)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for i in range(2):
+        assert (got[i] - want[i]).abs().max().item() <= 2e-5, f"thread {i}"
