@@ -21,12 +21,13 @@ namespace mtmc {
 // ------------------------------------------------------------------------------------------------
 // prep
 // ------------------------------------------------------------------------------------------------
+template <bool SPLIT>      // SPLIT: the kernel also carries operand-split jobs (64 more registers per lane: few-edge graphs only)
 __device__ void amax_jobs(const PrepParams& p, int block) {
   __shared__ float wmax[4];
   int j = 0;
   while (j + 1 < p.n_jobs && block >= p.jobs[j + 1].block0) ++j;      // every passenger workgroup serves ONE job
   const AmaxJob job = p.jobs[j];
-  if (job.kind == kJobSplit) {        // operand split (x planes of few-row graphs / the weight-plane cache): split_body.h
+  if (SPLIT && job.kind == kJobSplit) {        // operand split (x planes of few-row graphs / the weight-plane cache): split_body.h
     __shared__ unsigned long long fp_red[4];
     split_rows_body(job.ptr, job.ld, job.rows, job.cols, job.planes, job.rows * (int64_t)job.cols, job.inv, 0, job.rows,
                     block - job.block0, job.fp, fp_red);
@@ -58,12 +59,13 @@ __device__ void amax_jobs(const PrepParams& p, int block) {
   }
 }
 
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void prep_kernel(PrepParams p) {
   // passenger workgroups (operand scales / operand splits of the node encoder, the weight-plane cache's verification) come
   // FIRST in the grid: they are the longest (64 KB of reads each) and nothing else of the forward can start before the last
   // of them is done
   if ((int)blockIdx.x < p.n_pass_blocks) {
-    amax_jobs(p, blockIdx.x);
+    amax_jobs<SPLIT>(p, blockIdx.x);
     return;
   }
   const int eb = (int)blockIdx.x - p.n_pass_blocks;     // this workgroup's index among the edge workgroups
@@ -113,6 +115,10 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepParams p) {
   }
   block_atomic_add<5>(acc, p.stat_attr, kAttrStride, red, eb);
 }
+
+// The operand-split jobs by themselves (many-edge graphs: inside prep_kernel their 64 registers per lane cost the edge loop
+// three waves per SIMD of occupancy -- 67 -> 109 us at config 4, profiles/r05_cfg4_kernel_stats.csv before / after)
+__global__ __launch_bounds__(256) void split_jobs_kernel(PrepParams p) { amax_jobs<true>(p, blockIdx.x); }
 
 // ------------------------------------------------------------------------------------------------
 // edge encoder, hidden-layer moments
@@ -1567,9 +1573,7 @@ static inline int pick_ept(int64_t n_edges) { return n_edges <= kSmallEdges ? 1 
 #endif
 constexpr int kPassAEpt = MTMC_PASS_A_EPT;
 
-void launch_prep(const PrepParams& p0, hipStream_t s) {
-  PrepParams p = p0;
-  p.n_edge_blocks = p.n_edges > 0 ? edge_grid(p.n_edges, 256) : 0;
+static int size_jobs(PrepParams& p) {                    // block ranges of the passenger jobs; returns their total
   int extra = 0;
   for (int j = 0; j < p.n_jobs; ++j) {                  // ~16 float4 per lane, at most 2048 workgroups per operand
     const int64_t f4 = p.jobs[j].rows * (p.jobs[j].cols / 4), want = (f4 + 4095) / 4096;
@@ -1578,9 +1582,29 @@ void launch_prep(const PrepParams& p0, hipStream_t s) {
                                                      : (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
     extra += p.jobs[j].n_blocks;
   }
-  p.n_pass_blocks = extra;
-  if (p.n_edge_blocks + extra == 0) return;
-  hipLaunchKernelGGL(prep_kernel, dim3(p.n_edge_blocks + extra), dim3(256), 0, s, p);
+  return extra;
+}
+void launch_prep(const PrepParams& p0, hipStream_t s) {
+  PrepParams p = p0;
+  p.n_edge_blocks = p.n_edges > 0 ? edge_grid(p.n_edges, 256) : 0;
+  bool any_split = false;
+  for (int j = 0; j < p.n_jobs; ++j) any_split = any_split || p.jobs[j].kind == kJobSplit;
+  if (any_split && p.n_edges > kSmallEdges) {           // many edges: the split jobs in a launch of their own (see above)
+    PrepParams q = p0;
+    q.n_edges = 0; q.n_edge_blocks = 0; q.n_jobs = 0;
+    p.n_jobs = 0;
+    for (int j = 0; j < p0.n_jobs; ++j) {
+      if (p0.jobs[j].kind == kJobSplit) q.jobs[q.n_jobs++] = p0.jobs[j];
+      else p.jobs[p.n_jobs++] = p0.jobs[j];
+    }
+    q.n_pass_blocks = size_jobs(q);
+    hipLaunchKernelGGL(split_jobs_kernel, dim3(q.n_pass_blocks), dim3(256), 0, s, q);
+    any_split = false;
+  }
+  p.n_pass_blocks = size_jobs(p);
+  if (p.n_edge_blocks + p.n_pass_blocks == 0) return;
+  if (any_split) hipLaunchKernelGGL(prep_kernel<true>, dim3(p.n_edge_blocks + p.n_pass_blocks), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(prep_kernel<false>, dim3(p.n_edge_blocks + p.n_pass_blocks), dim3(256), 0, s, p);
 }
 void launch_enc2(const EdgeEncParams& enc, const float* attr, int64_t n_edges, double e_total, double* stat_enc2,
                  hipStream_t s) {
@@ -1713,16 +1737,11 @@ void launch_pass_c(const RoundParams& p0, hipStream_t s) {
     const int cap = max_blocks < 256 * 3 ? max_blocks : 256 * 3;           // 130 registers: three blocks per CU
     hipLaunchKernelGGL(pass_c_mfma_kernel, dim3((int)(blocks > cap ? cap : blocks)), dim3(256), 0, s, p, span_c);
   }
-  if (p.mfma_c != 2) {
-    // Behind a matrix-core kernel the walk only does the < 64 edges behind a sorted list's last whole chunk (one workgroup) --
-    // or, when prep_kernel found the rows unsorted (known on the device only: the launch cannot be skipped from the host), the
-    // whole round.  Rounds 3-4 launched the full grid of up to 2048 workgroups, 5 us of dispatch per round that only returned
-    // on every sorted list; now one workgroup per CU (grid-stride loop): 1/8 of the dispatch, and an UNSORTED many-edge list
-    // -- the exception: the reference's lists are row-sorted -- walks with 256 workgroups instead of 2048.
-    const int full = edge_grid(p.n_edges, kTileC);
-    const int grid = (p.mfma_c == 0) ? full : (full < 256 ? full : 256);
-    hipLaunchKernelGGL(pass_c_kernel, dim3(grid), dim3(kTileC), 0, s, p);
-  }
+  // (behind a matrix-core kernel the walk returns at once on sorted lists -- all but the workgroup that owns the < 64 edges
+  //  behind the last whole chunk.  Round 5 launched it with 256 workgroups instead of up to 2048 there: the launch still
+  //  took 5.3 us (5.1 before: it is the fixed cost of a dependent launch, not the dispatch of 2048 workgroups that return), and
+  //  an unsorted many-edge list would walk with an eighth of the workgroups -- reverted, profiles/r05_cfg4_kernel_stats.csv)
+  if (p.mfma_c != 2) hipLaunchKernelGGL(pass_c_kernel, dim3(edge_grid(p.n_edges, kTileC)), dim3(kTileC), 0, s, p);
   if (p.det && p.agg != 2) {
     const int64_t blocks = (p.n_nodes + 7) / 8;
     hipLaunchKernelGGL(agg_fixup_kernel, dim3((int)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks))), dim3(256), 0, s, p);

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Regenerates profiles/${ROUND}_* on a GPU box:  ROUND=r03 bash tools/refresh_profiles.sh   (run through gpurun; copies land in
+# Regenerates profiles/${ROUND}_* on a GPU box:  ROUND=r05 bash tools/refresh_profiles.sh   (run through gpurun; copies land in
 # gpurun_out/, move them to profiles/ afterwards).  kernel-trace/stats and each PMC counter are separate rocprofv3
 # passes, as the guide prescribes; the program after `--` is python3 itself.
 set -e
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof
 mkdir -p $OUT
