@@ -222,6 +222,8 @@ int32_t mtmc_mpn_forward(const mtmc_mpn_model* model, const mtmc_mpn_call* call)
     if ((rc = run_phase(xs, MTMC_PH_EDGE_ENC, 0))) return rc;
     if (hipEventRecord(sd->join, sd->stream) != hipSuccess) return fail(MTMC_E_HIP, "hipEventRecord failed");
   } else {
+    // (round 5 tried the edge part of prep_kernel as passenger of encoder layer 0, with the statistics head cleared by the operand
+    //  jobs' launch instead of a memset: layer 0 took 6 us longer, the jobs alone 8.0 us against prep_kernel's 8.8 -- DESIGN.md A.5)
     if ((rc = run_phase(x, MTMC_PH_BEGIN, 0))) return rc;
     x.enc2_rides = enc2_can_ride(x);              // few-row graphs: enc2 as passenger of the last encoder layer's launch
     if (!x.enc2_rides && (rc = run_phase(x, MTMC_PH_EDGE_ENC, 0))) return rc;

@@ -447,6 +447,16 @@ inline bool enc2_can_ride(const Ctx& x) {
 
 enum { kPhMemset = -1, kPhPrep = -2 };   // the two halves of MTMC_PH_BEGIN, for the forked forward
 
+// the edge part of prep_kernel for this call
+inline void fill_prep_edge(const Ctx& x, mtmc::PrepEdge* p) {
+  const mtmc_mpn_call* c = x.c;
+  p->row = c->row; p->col = c->col; p->idx_stride = c->idx_stride; p->attr = c->edge_attr; p->fe = x.m->enc_edge[0].in_dim;
+  p->n_edges = c->n_edges; p->n_nodes = c->n_nodes;
+  p->row32 = x.at<int>(x.lo.row32); p->col32 = x.at<int>(x.lo.col32); p->deg = x.at<int>(x.lo.pub.deg_off);
+  p->flags = x.at<int>(x.lo.pub.flags_off); p->stat_attr = x.at<double>(x.lo.pub.stat_attr_off);
+  p->row_start = x.at<int>(x.lo.row_start);
+}
+
 inline const int* scale_deg(const Ctx& x) {   // the degree mean aggregation divides by
   return x.at<int>((x.c->flags & MTMC_F_GLOBAL_DEG) ? x.lo.pub.deg_global_off : x.lo.pub.deg_off);
 }
@@ -467,11 +477,7 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
         return fail(MTMC_E_HIP, "hipMemsetAsync failed");
       if (phase != kPhMemset) {
         mtmc::PrepParams p;
-        p.row = c->row; p.col = c->col; p.idx_stride = c->idx_stride; p.attr = c->edge_attr; p.fe = m->enc_edge[0].in_dim;
-        p.n_edges = c->n_edges; p.n_nodes = c->n_nodes;
-        p.row32 = x.at<int>(x.lo.row32); p.col32 = x.at<int>(x.lo.col32); p.deg = x.at<int>(x.lo.pub.deg_off);
-        p.flags = x.at<int>(x.lo.pub.flags_off); p.stat_attr = x.at<double>(x.lo.pub.stat_attr_off);
-        p.row_start = x.at<int>(x.lo.row_start);
+        fill_prep_edge(x, &p);
         // passenger jobs: operand |.|max values / operand splits of the node encoder (this rank's rows of x; the weights)
         unsigned* amax = x.at<unsigned>(x.lo.amax);
         p.n_jobs = 0;

@@ -72,7 +72,10 @@ __global__ __launch_bounds__(512) void few_l0_kernel(FewL0Params p, int tiles_m,
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // column tiles in groups of cpx per XCD (blocks b, b + 8, ... share an XCD under round-robin placement: speed only)
   int tm, tn;
-  if (cpx > 0) {
+  if (cpx == -1) {                     // (experiment, MTMC_FEW_L0_MAP=1: 4 row tiles x 8 column tiles per XCD; 8 x 32 tiles only)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    tm = 4 * (xcd & 1) + (slot >> 3); tn = 8 * (xcd >> 1) + (slot & 7);
+  } else if (cpx > 0) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     tn = xcd * cpx + slot % cpx; tm = slot / cpx;
   } else {
@@ -221,10 +224,13 @@ bool few_l0_shape(int K, int Nout) { return K % 64 == 0 && K >= 64 && K <= 2048 
 int launch_few_l0(const FewL0Params& p, hipStream_t s) {
   if (p.M < 1 || !few_l0_shape(p.K, p.Nout) || !p.Ah || !p.Wh || !p.inv_a || !p.inv_w || !p.bias || !p.Y) return 1;
   const int tiles_m = (int)((p.M + kL0BM - 1) / kL0BM), tiles_n = p.Nout / kL0BN;
-  const int cpx = tiles_n >= 8 ? (tiles_n + 7) / 8 : 0;
-  const int grid = cpx > 0 ? 8 * cpx * tiles_m : tiles_n * tiles_m;
+  int cpx = tiles_n >= 8 ? (tiles_n + 7) / 8 : 0;
+  int grid = cpx > 0 ? 8 * cpx * tiles_m : tiles_n * tiles_m;
+  const int map = knobs().few_l0_map;          // A/B of the tile -> XCD binding
+  if (map == 1 && tiles_m == 8 && tiles_n == 32) cpx = -1;
+  if (map == 2) { cpx = 0; grid = tiles_n * tiles_m; }
   const size_t lds = (size_t)kL0Stages * kL0Stage;
-  if (!allow_big_lds(reinterpret_cast<const void*>(few_l0_kernel), 160 * 1024)) return MTMC_E_HIP;
+  if (!allow_big_lds(reinterpret_cast<const void*>(few_l0_kernel), (int)lds)) return MTMC_E_HIP;
   hipLaunchKernelGGL(few_l0_kernel, dim3(grid), dim3(512), lds, s, p, tiles_m, tiles_n, cpx);
   return MTMC_OK;
 }

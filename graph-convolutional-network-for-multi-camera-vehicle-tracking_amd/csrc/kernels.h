@@ -26,6 +26,7 @@ struct Knobs {
                              // 1, 2, 4, 8, 8, ... rounds of workgroups (default), 2 / 3 = uniform panels of 1 / 2 rounds
   bool gemm_no_few;          // MTMC_GEMM_NO_FEW: few-row graphs on the split-K in-loop kernels + combine (rounds 1-4; A/B)
   int few_rows_max;          // MTMC_FEW_ROWS_MAX: most node rows a call may encode on the few-row kernels (gemm_few.hip)
+  int few_l0_map;            // MTMC_FEW_L0_MAP: tile -> XCD binding of few_l0_kernel (0: column groups, 1: 4 x 8 tiles per XCD, 2: none)
   int few_wave_rb;           // MTMC_FEW_WAVE_RB: 16-row blocks per workgroup of few_wave_kernel (0: chosen per launch)
 };
 const Knobs& knobs();
@@ -40,15 +41,19 @@ enum { kJobAmax = 0, kJobSplit = 1 };
 struct AmaxJob { const float* ptr; int64_t rows; int cols; int64_t ld; unsigned* out; int block0, n_blocks;   // block range: set by launch_prep
                  int kind; _Float16* planes; float* inv; unsigned long long* fp; };
 
-struct PrepParams {
-  int n_edge_blocks, n_jobs;          // grid = passenger blocks working through jobs[] (first) + n_edge_blocks
-  int n_pass_blocks;                  // set by launch_prep
-  AmaxJob jobs[2 * MTMC_MAX_ENC_LAYERS + 2];
+// The edge part of prep_kernel: int64 strided edge_index -> int32 row / col, out-degree, sortedness flags, moments of edge_attr
+struct PrepEdge {
+  int n_edge_blocks = 0;              // workgroups that share the edge list (set by the launcher)
   const int64_t* row; const int64_t* col; int64_t idx_stride;
   const float* attr; int fe;
   int64_t n_edges; int64_t n_nodes;
   int* row32; int* col32; int* deg; int* flags; int* row_start;
   double* stat_attr;
+};
+struct PrepParams : PrepEdge {
+  int n_jobs;                         // grid = passenger blocks working through jobs[] (first) + n_edge_blocks
+  int n_pass_blocks;                  // set by launch_prep
+  AmaxJob jobs[2 * MTMC_MAX_ENC_LAYERS + 2];
 };
 
 // Everything one message-passing round needs (passes A, B, C).

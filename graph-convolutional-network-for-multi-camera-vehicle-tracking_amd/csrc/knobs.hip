@@ -30,6 +30,7 @@ static Knobs read_knobs() {
   k.gemm_no_few = on("MTMC_GEMM_NO_FEW");
   k.few_rows_max = (int)num("MTMC_FEW_ROWS_MAX", 1536);    // measured crossover: tools/few_crossover.py, profiles/r05_few_crossover.txt
   k.few_wave_rb = (int)num("MTMC_FEW_WAVE_RB", 0);
+  k.few_l0_map = (int)num("MTMC_FEW_L0_MAP", 0);
   return k;
 }
 

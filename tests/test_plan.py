@@ -60,7 +60,7 @@ def test_single_gpu_regimes(eng):
     assert s02.pass_c == _lib.PASS_C_MFMA_ANY and not s02.lazy_edges and s02.edges_per_thread == 1
     old = eng.plan(450, 150_454, weight_cache=False)   # ... without one (plain C callers, cache_weight_planes = False): rounds 1-4
     assert old.enc_kernel == [_lib.GEMM_INLOOP_64] * 4 and old.enc_split_k[:3] == [4, 4, 4] and old.enc_split_k[3] == 1
-    assert old.enc2_passenger
+    assert old.enc2_passenger and s02.enc2_passenger
     trk = eng.plan(1002, 751_202)                      # few rows AND more than 524288 edges
     assert trk.enc_kernel == [_lib.GEMM_FEW_L0] + [_lib.GEMM_FEW_WAVE] * 3
     trk_old = eng.plan(1002, 751_202, weight_cache=False)
