@@ -150,7 +150,7 @@ int32_t mtmc_mpn_plan_call(const mtmc_mpn_model* model, const mtmc_mpn_call* cal
                     mtmc::presplit_layer0(rows, model->enc_node[0].in_dim, model->enc_node[0].out_dim);
   CacheLayout cl;
   make_cache_layout(model, &cl);
-  bool few = !c->training && c->weight_cache != nullptr && few_shape(model, c->n_nodes) && few_shape(model, rows);   // use_few
+  bool few = c->weight_cache != nullptr && few_shape(model, c->n_nodes) && few_shape(model, rows);   // use_few (training too)
   for (int l = 0; l < model->n_enc_layers; ++l) few = few && cl.has[l];
   for (int l = 0; l < model->n_enc_layers; ++l) {
     const mtmc_layer& L = model->enc_node[l];

@@ -153,7 +153,7 @@ inline void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* l
   // Layer 0 of a many-row graph runs on operands split ONCE into fp16 pairs (gemm_presplit.hip): planes of x [2][N][K]
   // and of W0 [2][out][K] plus one power-of-two scale per row.  An x-sized region; eval mode only.
   lo->presplit0 = !training && mtmc::presplit_layer0(N, m->enc_node[0].in_dim, m->enc_node[0].out_dim);
-  lo->few = !training && few_shape(m, N);     // (the call also needs a weight-plane cache: use_few)
+  lo->few = few_shape(m, N);                  // (the call also needs a weight-plane cache: use_few; training forwards too)
   if (lo->presplit0 || lo->few) {
     const size_t K0 = m->enc_node[0].in_dim, O0 = m->enc_node[0].out_dim;
     lo->xh = take((size_t)2 * N * K0 * sizeof(uint16_t));
@@ -274,7 +274,7 @@ inline int make_ctx(const mtmc_mpn_model* m, const mtmc_mpn_call* c, Ctx* ctx) {
   ctx->ws = static_cast<char*>(c->workspace);
   ctx->stream = static_cast<hipStream_t>(c->stream);
   make_cache_layout(m, &ctx->cl);
-  if (c->weight_cache && !c->training) {
+  if (c->weight_cache) {
     if ((uintptr_t)c->weight_cache & 255) return fail(MTMC_E_WORKSPACE, "weight_cache must be 256-byte aligned");
     if (c->weight_cache_bytes < ctx->cl.total)
       return fail(MTMC_E_WORKSPACE, "weight_cache has %zu bytes, %zu needed (mtmc_mpn_weight_cache_bytes)", c->weight_cache_bytes, ctx->cl.total);
@@ -398,7 +398,7 @@ inline bool use_rows(const Ctx& x, int l) {
 
 // every layer on the few-row kernels (gemm_few.hip): eval mode, a weight-plane cache, few rows here AND in the whole graph
 inline bool use_few(const Ctx& x) {
-  if (!x.lo.few || !x.wc || x.c->training) return false;
+  if (!x.lo.few || !x.wc) return false;
   for (int l = 0; l < x.m->n_enc_layers; ++l) if (!x.cl.has[l]) return false;
   return few_shape(x.m, x.c->node_hi - x.c->node_lo);
 }
@@ -483,14 +483,17 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
         p.n_jobs = 0;
         const bool pre0 = use_presplit0(x), few = use_few(x);
         const int64_t rows = c->node_hi - c->node_lo;
+        // (training forwards: the jobs also publish the tensors' |.|max -- the backward's GEMMs scale by |x|max and |W_l|max)
+        unsigned* amax_w0 = x.at<unsigned>(x.lo.amax_w);
         auto cache_job = [&](int l) {     // layer l's planes in the cache: verify every 8-row chunk, split the ones that changed
-          p.jobs[p.n_jobs++] = {m->enc_node[l].weight, m->enc_node[l].out_dim, m->enc_node[l].in_dim, m->enc_node[l].in_dim, nullptr, 0, 0,
+          p.jobs[p.n_jobs++] = {m->enc_node[l].weight, m->enc_node[l].out_dim, m->enc_node[l].in_dim, m->enc_node[l].in_dim,
+                                c->training ? amax_w0 + l * mtmc::kAmaxRep : nullptr, 0, 0,
                                 mtmc::kJobSplit, x.wc_at<_Float16>(x.cl.planes[l]), x.wc_at<float>(x.cl.inv[l]),
                                 x.wc_at<unsigned long long>(x.cl.fp[l])};
         };
         if (rows > 0) {
           if (few)         // the planes of x, 8 rows per passenger workgroup (no |x|max: one scale per row)
-            p.jobs[p.n_jobs++] = {c->x, rows, m->enc_node[0].in_dim, c->x_row_stride, nullptr, 0, 0, mtmc::kJobSplit,
+            p.jobs[p.n_jobs++] = {c->x, rows, m->enc_node[0].in_dim, c->x_row_stride, c->training ? amax : nullptr, 0, 0, mtmc::kJobSplit,
                                   x.at<_Float16>(x.lo.xh), x.at<float>(x.lo.inv_a), nullptr};
           else if (!pre0)
             p.jobs[p.n_jobs++] = {c->x, rows, m->enc_node[0].in_dim, c->x_row_stride, amax, 0, 0, mtmc::kJobAmax, nullptr, nullptr, nullptr};
@@ -555,6 +558,7 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
           q.bias = Lr.bias; q.Y = x.at<float>(x.lo.Y[arg]); q.ldy = Lr.out_dim;
           q.stats_out = x.at<double>(x.lo.stat_enc_layer[arg]);
           q.M = rows; q.K = Lr.in_dim; q.Nout = Lr.out_dim;
+          q.drop_in = make_drop(x, m->dropout_enc); q.drop_stream = mtmc::kDropEncNode + arg - 1;
           if (x.enc2_rides && arg == m->n_enc_layers - 1) {
             const int64_t blocks = (c->n_edges + 255) / 256;
             q.pass_blocks = (int)(blocks > 2048 ? 2048 : blocks);

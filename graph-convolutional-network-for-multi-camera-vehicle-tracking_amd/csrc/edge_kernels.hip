@@ -31,7 +31,7 @@ __device__ void amax_jobs(const PrepParams& p, int block) {
   if (SPLIT && job.kind == kJobSplit) {        // operand split (x planes of few-row graphs / the weight-plane cache): split_body.h
     __shared__ unsigned long long fp_red[4];
     split_rows_body(job.ptr, job.ld, job.rows, job.cols, job.planes, job.rows * (int64_t)job.cols, job.inv, 0, job.rows,
-                    block - job.block0, job.fp, fp_red);
+                    block - job.block0, job.fp, fp_red, job.out);
     return;
   }
   const int c4n = job.cols / 4;                         // cols is a multiple of 32 (check_model)

@@ -252,7 +252,8 @@ __device__ __forceinline__ float wave_max_nonneg(float v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
-template <int NKB, int CB, int RB>     // k-steps of 32 per wave; 16-column blocks and 16-row blocks per workgroup
+// DROP: the encoder's Dropout on the A operand compiled in (training; counter-based, as in gemm_bn_f16x3_kernel)
+template <int NKB, int CB, int RB, bool DROP>     // k-steps of 32 per wave; 16-column blocks and 16-row blocks per workgroup
 __global__ __launch_bounds__(512) void few_wave_kernel(FewWaveParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if ((int)blockIdx.x >= p.tiles) {                       // passenger workgroups (256 threads): the edge encoder's enc2 job
@@ -297,9 +298,11 @@ __global__ __launch_bounds__(512) void few_wave_kernel(FewWaveParams p) {
     }
   }
   float4 av[RB][NKB][2];
+  int64_t arows[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     const int64_t arow = row0 + 16 * rb + i16 < p.M ? row0 + 16 * rb + i16 : p.M - 1;
+    arows[rb] = arow;
     const float* asrc = p.A + arow * p.lda + k0 + 8 * g;
 #pragma unroll
     for (int s = 0; s < NKB; ++s) {
@@ -340,6 +343,7 @@ __global__ __launch_bounds__(512) void few_wave_kernel(FewWaveParams p) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         xv[s][j] = fmaxf(fmaf(x[j], sv[j], tv[j]), 0.f);
+        if (DROP) xv[s][j] = drop_apply(p.drop_in, p.drop_stream, (unsigned long long)arows[rb] * p.K + k0 + 32 * s + 8 * g + j, xv[s][j]);
         m = fmaxf(m, xv[s][j]);
       }
     }
@@ -458,12 +462,19 @@ int launch_few_wave(const FewWaveParams& p0, hipStream_t s) {
   if (!carries) p.pass_blocks = 0;
   const size_t lds = (size_t)nw * 2 * 32 * nkb * sizeof(float) + (size_t)nw * rb * cb * 64 * sizeof(f32x4v);
   const dim3 grid(p.tiles + p.pass_blocks), block(64 * nw);
-  if (nkb == 4 && cb == 2 && rb == 2) hipLaunchKernelGGL((few_wave_kernel<4, 2, 2>), grid, block, lds, s, p);
-  else if (nkb == 4 && cb == 2) hipLaunchKernelGGL((few_wave_kernel<4, 2, 1>), grid, block, lds, s, p);
-  else if (nkb == 4) hipLaunchKernelGGL((few_wave_kernel<4, 1, 1>), grid, block, lds, s, p);
-  else if (nkb == 1 && cb == 2) hipLaunchKernelGGL((few_wave_kernel<1, 2, 1>), grid, block, lds, s, p);
-  else if (nkb == 1) hipLaunchKernelGGL((few_wave_kernel<1, 1, 1>), grid, block, lds, s, p);
-  else hipLaunchKernelGGL((few_wave_kernel<8, 1, 1>), grid, block, lds, s, p);
+  const bool drop = p.drop_in.on != 0;
+#define FEW_WAVE_LAUNCH(A, B, C)                                                                        \
+  do {                                                                                                  \
+    if (drop) hipLaunchKernelGGL((few_wave_kernel<A, B, C, true>), grid, block, lds, s, p);             \
+    else hipLaunchKernelGGL((few_wave_kernel<A, B, C, false>), grid, block, lds, s, p);                 \
+  } while (0)
+  if (nkb == 4 && cb == 2 && rb == 2) FEW_WAVE_LAUNCH(4, 2, 2);
+  else if (nkb == 4 && cb == 2) FEW_WAVE_LAUNCH(4, 2, 1);
+  else if (nkb == 4) FEW_WAVE_LAUNCH(4, 1, 1);
+  else if (nkb == 1 && cb == 2) FEW_WAVE_LAUNCH(1, 2, 1);
+  else if (nkb == 1) FEW_WAVE_LAUNCH(1, 1, 1);
+  else FEW_WAVE_LAUNCH(8, 1, 1);
+#undef FEW_WAVE_LAUNCH
   if (job_behind) launch_enc2(p0.pass_enc, p0.pass_attr, p0.pass_edges, p0.pass_e_total, p0.pass_stat, s);
   return MTMC_OK;
 }

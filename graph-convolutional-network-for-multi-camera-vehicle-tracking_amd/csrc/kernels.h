@@ -166,6 +166,7 @@ struct FewWaveParams {
   float* Y; int64_t ldy;
   double* stats_out;                        // f64[2*Nout], accumulated atomically (or nullptr)
   int64_t M; int K; int Nout;
+  Drop drop_in = {0, 0, 1.f, 0}; unsigned drop_stream = 0;   // training: Dropout applied with the input BatchNorm + ReLU
   int tiles = 0;                            // set by launch_few_wave
   // passenger workgroups as in GemmParams (the edge encoder's enc2 job rides in the last layer's launch)
   int pass_blocks = 0; EdgeEncParams pass_enc = {}; const float* pass_attr = nullptr; int64_t pass_edges = 0;

@@ -28,7 +28,7 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 __device__ __forceinline__ void split_rows_body(const float* __restrict__ X, int64_t ld, int64_t rows, int K,
                                                 _Float16* __restrict__ H, int64_t plane, float* __restrict__ inv,
                                                 int64_t r_lo, int64_t r_hi, int chunk, unsigned long long* __restrict__ fp,
-                                                unsigned long long* smem) {
+                                                unsigned long long* smem, unsigned* amax_out = nullptr) {
   const int lane = threadIdx.x & 63, l = lane & 31;
   const int64_t row = r_lo + ((int64_t)chunk * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
   const bool live = row < r_hi;
@@ -48,6 +48,12 @@ __device__ __forceinline__ void split_rows_body(const float* __restrict__ X, int
     }
     m = fmaxf(m, fmaxf(fmaxf(fabsf(v[j][0].x), fabsf(v[j][0].y)), fmaxf(fabsf(v[j][0].z), fabsf(v[j][0].w))));
     m = fmaxf(m, fmaxf(fmaxf(fabsf(v[j][1].x), fabsf(v[j][1].y)), fmaxf(fabsf(v[j][1].z), fabsf(v[j][1].w))));
+  }
+  if (amax_out) {       // training forwards: the backward's GEMMs scale by the tensor's |.|max (u32[kAmaxRep] bit patterns)
+    float mw = live ? m : 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mw = fmaxf(mw, __shfl_xor(mw, off, 64));
+    if (lane == 0 && mw > 0.f) atomicMax(amax_out + (chunk & 15), __float_as_uint(mw));
   }
   unsigned long long mine = 0;
   if (fp) {

@@ -264,7 +264,7 @@ class ForwardEngine:
         call.training, call.seed = (1 if tape else 0), int(seed) & 0xFFFFFFFFFFFFFFFF
         call.flags = int(self.flags) | (_lib.F_DETERMINISTIC if getattr(self.module, "deterministic", False) else 0)
         keep = (x, edge_index, edge_attr)        # the structs hold raw pointers: keep the tensors alive
-        if self.weight_cache and not tape and tape_ws is None:
+        if self.weight_cache and tape_ws is None:      # (training forwards too: every chunk whose weights the step changed is split again)
             wc = self.weight_plane_cache(model, dev, stream)
             call.weight_cache, call.weight_cache_bytes = wc.data_ptr(), wc.numel()
             keep = keep + (wc,)
@@ -286,7 +286,7 @@ class ForwardEngine:
             rlo, rhi = int(row_range[0]), int(row_range[1])
             call.row_lo, call.row_hi = (rlo, rhi) if rhi > rlo else (max(rlo, 1), max(rlo, 1))
         call.training, call.flags = int(bool(training)), int(flags)
-        if weight_cache and not training:              # (tested for NULL by the query, never read)
+        if weight_cache:                               # (tested for NULL by the query, never read)
             call.weight_cache, call.weight_cache_bytes = 256, 1 << 62
         out = _lib.Plan()
         _lib.check(self.lib.mtmc_mpn_plan_call(C.byref(model), C.byref(call), C.byref(out)))

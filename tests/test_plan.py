@@ -86,7 +86,8 @@ def test_single_gpu_regimes(eng):
     assert det_small.pass_c == _lib.PASS_C_WALK         # few edges: fixed-order aggregation lives in the walk
     trn = eng.plan(440, 180_000, training=True)
     assert trn.pass_c == _lib.PASS_C_WALK and not trn.lazy_edges     # Dropout in the node update; e' kept for the tape
-    assert trn.enc_kernel == [_lib.GEMM_INLOOP_64] * 4                # training: the in-loop kernels (no cache, Dropout)
+    assert trn.enc_kernel == [_lib.GEMM_FEW_L0] + [_lib.GEMM_FEW_WAVE] * 3     # training forwards take the few-row kernels too (Dropout compiled in)
+    assert eng.plan(440, 180_000, training=True, weight_cache=False).enc_kernel == [_lib.GEMM_INLOOP_64] * 4
 
 
 def test_deterministic_mode_beyond_the_sorted_kernels_node_limit(eng):
