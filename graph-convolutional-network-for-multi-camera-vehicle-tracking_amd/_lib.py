@@ -76,7 +76,7 @@ PASS_C_WALK, PASS_C_MFMA_SORTED, PASS_C_MFMA_ANY = range(3)
 # statistics blocks (include/mtmc_mpn.h): replicas x stride doubles each
 STAT_REPLICAS, ATTR_STRIDE, ENC2_STRIDE, Z1_STRIDE, M_STRIDE, Z2_STRIDE = 16, 16, 16, 16, 16, 64
 ROUND_BLOCK = STAT_REPLICAS * (Z1_STRIDE + M_STRIDE + Z2_STRIDE)
-F_DETERMINISTIC, F_GLOBAL_DEG, F_FORK = 1, 4, 2
+F_DETERMINISTIC, F_GLOBAL_DEG, F_FORK, F_SEED_ON_DEVICE = 1, 4, 2, 16
 
 # MTMC_MPN_LIB: another build of the same ABI (same-box A/B of two library versions, tools/lib_ab.sh); default: the in-tree build
 LIB_PATH = os.environ.get("MTMC_MPN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmtmc_mpn.so")

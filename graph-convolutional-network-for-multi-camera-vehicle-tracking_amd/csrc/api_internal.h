@@ -48,7 +48,8 @@ struct Layout {
   size_t bwd_zero, bwd_zero_end;               // the range the backward clears with one memset
   size_t gacc;                                 // f32[kGradRep][kGaccN] (train_kernels.h)
   size_t amax_bwd;                             // u32[2][MTMC_MAX_ENC_LAYERS][kAmaxRep] (zeroed with the backward scratch)
-  size_t gA, gB, tA, tB, tW, zeros, bst_n;     // node-encoder backward: gradient ping-pong, transposes, 0-bias, column stats
+  size_t seed_word = 0;
+  size_t gA, gB, tA, tB, tW, tX, zeros, bst_n; // node-encoder backward: gradient ping-pong, transposes, 0-bias, column stats
 };
 constexpr int kBwdStride = 256;                // doubles per replica of the backward statistics scratch
 
@@ -130,6 +131,7 @@ inline void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* l
   lo->pub.h_acc_off[0] = take((size_t)N * 32 * sizeof(float));
   lo->pub.h_acc_off[1] = take((size_t)N * 32 * sizeof(float));
   lo->enc_aff = take(16 * sizeof(float));
+  lo->seed_word = take(sizeof(unsigned long long));     // MTMC_F_SEED_ON_DEVICE: this forward's Dropout seed (stays on the tape)
   lo->row_start = take((size_t)N * sizeof(int32_t));
   lo->carry = take((size_t)((E + 31) / 32) * 2 * 32 * sizeof(float));
   lo->col_blocks = mtmc::plan_col_blocks(N, E, 1e30, training);      // by table size and edge count alone (the call adds the degree)
@@ -207,7 +209,10 @@ inline void make_layout(const mtmc_mpn_model* m, int64_t N, int64_t E, Layout* l
     lo->gB = take((size_t)N * maxd * sizeof(float));
     lo->tA = take(npad * maxd * sizeof(float));
     lo->tB = take(npad * maxd * sizeof(float));
-    lo->tW = take(maxd * maxd * sizeof(float));
+    size_t wsum = 0;                                   // every W_l^T and x^T at once: one transpose launch (api_train.hip)
+    for (int l = 0; l < m->n_enc_layers; ++l) wsum += (size_t)m->enc_node[l].in_dim * m->enc_node[l].out_dim;
+    lo->tW = take(wsum * sizeof(float));
+    lo->tX = take(npad * (size_t)m->enc_node[0].in_dim * sizeof(float));
   }
   lo->pub.total_bytes = off;
 }
@@ -251,6 +256,8 @@ inline int make_ctx(const mtmc_mpn_model* m, const mtmc_mpn_call* c, Ctx* ctx) {
   if (int rc = check_call_size(c)) return rc;
   if (c->training && (c->node_lo != 0 || c->node_hi != c->n_nodes || c->n_edges_total != c->n_edges))
     return fail(MTMC_E_ARG, "training mode is single-shard only");
+  if (c->training && (c->flags & MTMC_F_SEED_ON_DEVICE) && (c->seed == 0 || (c->seed & 7)))
+    return fail(MTMC_E_ARG, "MTMC_F_SEED_ON_DEVICE: seed must hold the 8-byte aligned device address of a uint64 counter");
   if (c->n_nodes < 2) return fail(MTMC_E_ROWS, "BatchNorm over %lld node rows: Expected more than 1 value per channel", (long long)c->n_nodes);
   if (c->n_edges_total < 2) return fail(MTMC_E_ROWS, "BatchNorm over %lld edge rows: Expected more than 1 value per channel", (long long)c->n_edges_total);
   if (c->n_edges < 0 || c->n_edges > c->n_edges_total || c->n_edges >= (1ll << 31) || c->n_nodes >= (1ll << 31))
@@ -287,6 +294,10 @@ inline mtmc::Drop make_drop(const Ctx& x, float p) {
   mtmc::Drop d;
   d.on = (x.c->training && p > 0.f) ? 1 : 0;
   d.seed = x.c->seed;
+  if (d.on && (x.c->flags & MTMC_F_SEED_ON_DEVICE)) {   // the seed word of this forward, on the tape (seed_tick_kernel)
+    d.on = 2;
+    d.seed = (unsigned long long)(uintptr_t)(x.ws + x.lo.seed_word);
+  }
   const double t = (double)p * 4294967296.0;
   d.thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
   d.inv_keep = p < 1.f ? 1.f / (1.f - p) : 0.f;
@@ -475,6 +486,8 @@ inline int run_phase(const Ctx& x, int phase, int arg, bool fused_h0 = false) {
       // workgroups of prep_kernel (split_body.h); without a cache it is made per call in the workspace.
       if (phase != kPhPrep && hipMemsetAsync(x.ws, 0, x.lo.pub.zero_bytes, s) != hipSuccess)
         return fail(MTMC_E_HIP, "hipMemsetAsync failed");
+      if (phase != kPhPrep && c->training && (c->flags & MTMC_F_SEED_ON_DEVICE))      // seed word <- counter++ (one thread)
+        mtmc::launch_seed_tick(reinterpret_cast<unsigned long long*>((uintptr_t)c->seed), x.at<unsigned long long>(x.lo.seed_word), s);
       if (phase != kPhMemset) {
         mtmc::PrepParams p;
         fill_prep_edge(x, &p);

@@ -52,8 +52,32 @@ static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
   // One memset when the caller carved all of them out of one buffer (grads_flat), else one per tensor; the node
   // encoder's weight gradients are plain GEMM outputs and need none.
   auto zero = [&](float* p, size_t n) { return hipMemsetAsync(p, 0, n * sizeof(float), s); };
+  bool ws_zeroed = false;
   if (grads_flat) {
-    HIP_OK(hipMemsetAsync(grads_flat, 0, grads_flat_bytes, s));
+    // one launch for the flat buffer's accumulated pieces (everything but the encoder's weight gradients, which must lie in it
+    // in layer order, as mtmc_mpn_grad_layout lays them out) and the workspace's range; anything else: plain memsets
+    mtmc::ZeroRanges z;
+    char* at = static_cast<char*>(grads_flat);
+    char* const end = at + grads_flat_bytes;
+    bool ok = ((uintptr_t)at & 15) == 0 && (grads_flat_bytes & 15) == 0;
+    for (int l = 0; ok && l < m->n_enc_layers; ++l) {
+      char* w = reinterpret_cast<char*>(const_cast<float*>(grads->enc_node[l].weight));
+      const size_t wb = (size_t)m->enc_node[l].in_dim * m->enc_node[l].out_dim * sizeof(float);
+      ok = w >= at && w + wb <= end && ((uintptr_t)w & 15) == 0 && (wb & 15) == 0;
+      if (ok && w > at) { z.r[z.n].p = reinterpret_cast<uint4*>(at); z.r[z.n].n16 = (size_t)(w - at) / 16; ++z.n; }
+      at = w + wb;
+    }
+    if (ok) {
+      if (end > at) { z.r[z.n].p = reinterpret_cast<uint4*>(at); z.r[z.n].n16 = (size_t)(end - at) / 16; ++z.n; }
+      ok = ((uintptr_t)(x.ws + lo.bwd_zero) & 15) == 0 && ((lo.bwd_zero_end - lo.bwd_zero) & 15) == 0;
+    }
+    if (ok) {
+      z.r[z.n].p = reinterpret_cast<uint4*>(x.ws + lo.bwd_zero); z.r[z.n].n16 = (lo.bwd_zero_end - lo.bwd_zero) / 16; ++z.n;
+      mtmc::launch_zero_ranges(z, s);
+      ws_zeroed = true;
+    } else {
+      HIP_OK(hipMemsetAsync(grads_flat, 0, grads_flat_bytes, s));
+    }
   } else {
     for (int l = 0; l < m->n_enc_layers; ++l) {
       const mtmc_layer& g = grads->enc_node[l];
@@ -70,7 +94,7 @@ static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
     }
   }
   // the workspace side: statistics blocks, per-round dP/dQ, dh0, de0, the first de / dh buffers -- one range
-  HIP_OK(hipMemsetAsync(x.ws + lo.bwd_zero, 0, lo.bwd_zero_end - lo.bwd_zero, s));
+  if (!ws_zeroed) HIP_OK(hipMemsetAsync(x.ws + lo.bwd_zero, 0, lo.bwd_zero_end - lo.bwd_zero, s));
   int cur = 0, cur_e = 0;
   if (d_h) HIP_OK(hipMemcpyAsync(L > 0 ? g_h[cur] : g_h0, d_h, (size_t)N * 32 * sizeof(float), hipMemcpyDeviceToDevice, s));
   if (L == 0 && d_logits_steps && d_logits_steps[0] && E > 0)       // no rounds: classifier on the encoded edges
@@ -146,18 +170,31 @@ static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
     float* tW = x.at<float>(lo.tW);
     float* zeros = x.at<float>(lo.zeros);
     const int64_t npad = (N + 31) / 32 * 32;
-    size_t maxd = 0;
-    for (int l = 0; l < m->n_enc_layers; ++l) maxd = std::max(maxd, (size_t)std::max(m->enc_node[l].in_dim, m->enc_node[l].out_dim));
-    HIP_OK(hipMemcpyAsync(gA, g_h0, (size_t)N * 32 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // x^T and every W_l^T the loop below multiplies by: known before its first kernel, one launch for all of them
+    float* tWl[MTMC_MAX_ENC_LAYERS] = {};
+    float* tX = x.at<float>(lo.tX);
+    {
+      mtmc::TransposeJobs tj;
+      mtmc::transpose_jobs_add(tj, call->x, N, m->enc_node[0].in_dim, call->x_row_stride, tX, npad);
+      float* w = tW;
+      for (int l = 0; l < m->n_enc_layers; ++l) {
+        const mtmc_layer& Lr = m->enc_node[l];
+        if (l > 0 || d_x) { tWl[l] = w; mtmc::transpose_jobs_add(tj, Lr.weight, Lr.out_dim, Lr.in_dim, Lr.in_dim, w, Lr.out_dim); }
+        w += (size_t)Lr.in_dim * Lr.out_dim;
+      }
+      mtmc::launch_transpose_multi(tj, s);
+    }
     const mtmc::Drop nodrop = {0, 0, 1.f, 0};
     for (int l = m->n_enc_layers - 1; l >= 0; --l) {
       const mtmc_layer& Lr = m->enc_node[l];
       const int d = Lr.out_dim, in = Lr.in_dim;
+      // dh0 is the last layer's dA: bn_bwd turns it into dY in place, where the edge rounds' backward left it
+      float* dY = (l == m->n_enc_layers - 1) ? g_h0 : gA;
       size_t sb_off = 0;
       for (int j = 0; j < l; ++j) sb_off += 2 * (size_t)m->enc_node[j].out_dim;
       double* sb = x.at<double>(lo.bst_n) + sb_off;
       mtmc::BnBwdParams bb;
-      bb.Y = x.at<float>(lo.Y[l]); bb.dA = gA; bb.rows = N; bb.dim = d;
+      bb.Y = x.at<float>(lo.Y[l]); bb.dA = dY; bb.rows = N; bb.dim = d;
       bb.stats_fwd = x.at<double>(lo.stat_enc_layer[l]); bb.stats_bwd = sb; bb.count = (double)N;
       bb.gamma = Lr.gamma; bb.beta = Lr.beta; bb.drop = make_drop(x, m->dropout_enc); bb.drop_stream = mtmc::kDropEncNode + l;
       bb.gr_gamma = const_cast<float*>(grads->enc_node[l].gamma); bb.gr_beta = const_cast<float*>(grads->enc_node[l].beta);
@@ -170,30 +207,26 @@ static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
       bb.amax_out = amax_dy;
       bb.dT = tA; bb.ldt = npad;                                       // dY_l^T comes out of the apply pass directly
       mtmc::launch_bn_bwd(bb, 0, s);
-      mtmc::launch_bn_bwd(bb, 1, s);                                   // gA now holds dY_l
+      mtmc::launch_bn_bwd(bb, 1, s);                                   // dY now holds dY_l
       // the layer's input activation a_{l-1}: x itself, or relu(bn(Y_{l-1})) with its dropout mask
-      const float* a_in = call->x;
-      int64_t lda = call->x_row_stride;
+      const float* aT = tX;                                            // a_{l-1}^T [in][npad]
       if (l > 0) {
         const mtmc_layer& Pv = m->enc_node[l - 1];
         mtmc::launch_bn_relu_rows(x.at<float>(lo.Y[l - 1]), Pv.out_dim, N, Pv.out_dim, x.at<double>(lo.stat_enc_layer[l - 1]),
                                   Pv.gamma, Pv.beta, (double)N, gB, make_drop(x, m->dropout_enc), mtmc::kDropEncNode + l - 1, 0, s,
                                   amax_act, tB, npad);               // ... and a_{l-1}^T out of its recomputation
-        a_in = gB; lda = in;
-      } else {
-        mtmc::launch_transpose_pad(a_in, N, in, lda, tB, npad, s);     // x^T
+        aT = tB;
       }
       // dW_l [d][in] = dY^T . a  -> NT GEMM on the transposes (reduction over the node rows, padded to 32)
       mtmc::GemmParams g;
-      g.A = tA; g.lda = npad; g.W = tB; g.bias = zeros; g.Y = const_cast<float*>(grads->enc_node[l].weight); g.ldy = in;
+      g.A = tA; g.lda = npad; g.W = aT; g.bias = zeros; g.Y = const_cast<float*>(grads->enc_node[l].weight); g.ldy = in;
       g.stats_in = nullptr; g.gamma_in = nullptr; g.beta_in = nullptr; g.count = 1; g.stats_out = nullptr;
       g.M = d; g.K = (int)npad; g.Nout = in; g.drop_in = nodrop; g.drop_stream = 0; g.slab = nullptr; g.split_k = 1;
       g.amax_a = amax_dy; g.amax_w = l > 0 ? amax_act : amax_fwd; g.amax_y = nullptr;
       if (mtmc::launch_gemm_bn(g, s) != MTMC_OK) return fail(MTMC_E_ARG, "backward: weight-gradient GEMM shape");
       // dA_{l-1} [N][in] = dY . W_l  -> NT GEMM against W^T
       if (l > 0 || d_x) {
-        mtmc::launch_transpose_pad(Lr.weight, d, in, in, tW, d, s);   // tW [in][d]
-        g.A = gA; g.lda = d; g.W = tW; g.Y = l > 0 ? gB : d_x; g.ldy = in; g.M = N; g.K = d; g.Nout = in;
+        g.A = dY; g.lda = d; g.W = tWl[l]; g.Y = l > 0 ? gB : d_x; g.ldy = in; g.M = N; g.K = d; g.Nout = in;    // W_l^T [in][d]
         g.amax_w = x.at<unsigned>(lo.amax_w) + (size_t)l * mtmc::kAmaxRep;
         if (mtmc::launch_gemm_bn(g, s) != MTMC_OK) return fail(MTMC_E_ARG, "backward: input-gradient GEMM shape");
         std::swap(gA, gB);

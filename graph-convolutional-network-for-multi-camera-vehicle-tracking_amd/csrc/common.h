@@ -250,7 +250,13 @@ static __device__ unsigned long long g_ek[kEkKernels * 2 * kEkPoints];
 // Dropout (training mode only; reference models/mlp.py:21-22): counter-based, so any kernel -- forward or
 // backward, or the CPU model in tests/ -- regenerates the same mask from (seed, stream, element index).
 // keep iff hash >= thresh, thresh = p * 2^32; kept values are scaled by 1/(1-p).
+// on == 2 (MTMC_F_SEED_ON_DEVICE): `seed` is the ADDRESS of the seed word of this forward in the workspace / tape (written by
+// seed_tick_kernel at the start of the forward from the caller's device counter), so that a HIP graph that holds the whole
+// training step draws new masks on every replay; the backward of the same tape reads the same word.
 struct Drop { unsigned long long seed; unsigned thresh; float inv_keep; int on; };
+__device__ __forceinline__ unsigned long long drop_seed(const Drop& d) {
+  return d.on == 2 ? *reinterpret_cast<const unsigned long long*>(d.seed) : d.seed;      // (uniform: a scalar load)
+}
 
 __host__ __device__ __forceinline__ unsigned drop_hash(unsigned long long seed, unsigned stream, unsigned long long idx) {
   unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull + (unsigned long long)stream * 0xBF58476D1CE4E5B9ull;
@@ -260,11 +266,11 @@ __host__ __device__ __forceinline__ unsigned drop_hash(unsigned long long seed, 
   return (unsigned)(z >> 32);
 }
 __device__ __forceinline__ bool drop_keep(const Drop& d, unsigned stream, unsigned long long idx) {
-  return !d.on || drop_hash(d.seed, stream, idx) >= d.thresh;
+  return !d.on || drop_hash(drop_seed(d), stream, idx) >= d.thresh;
 }
 __device__ __forceinline__ float drop_apply(const Drop& d, unsigned stream, unsigned long long idx, float v) {
   if (!d.on) return v;
-  return drop_hash(d.seed, stream, idx) >= d.thresh ? v * d.inv_keep : 0.f;
+  return drop_hash(drop_seed(d), stream, idx) >= d.thresh ? v * d.inv_keep : 0.f;
 }
 // stream ids
 constexpr unsigned kDropEncEdge1 = 1, kDropEncEdge2 = 2, kDropEncNode = 100, kDropRound = 1000;   // +layer / +2r(+1)

@@ -76,6 +76,13 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepParams p) {
 // three waves per SIMD of occupancy -- 67 -> 109 us at config 4, profiles/r05_cfg4_kernel_stats.csv before / after)
 __global__ __launch_bounds__(256) void split_jobs_kernel(PrepParams p) { amax_jobs<true>(p, blockIdx.x); }
 
+// MTMC_F_SEED_ON_DEVICE: this forward's Dropout seed = the caller's device counter, which moves on by one
+__global__ void seed_tick_kernel(unsigned long long* counter, unsigned long long* word) {
+  const unsigned long long v = *counter;
+  *word = v;
+  *counter = v + 1;
+}
+
 // ------------------------------------------------------------------------------------------------
 // edge encoder, hidden-layer moments
 // ------------------------------------------------------------------------------------------------
@@ -1649,6 +1656,9 @@ int plan_pass_c(int agg, bool deterministic, bool dropout, int64_t n_edges, int6
   if (n_edges > kSmallEdges) return (deterministic && (kn.pass_c_general || n_nodes >= kSortedMaxNodes)) ? 0 : 1;
   if (deterministic) return 0;                               // few edges: fixed-order sums live in the walk
   return n_edges >= kn.pass_c_small_min ? 2 : 0;
+}
+void launch_seed_tick(unsigned long long* counter, unsigned long long* word, hipStream_t s) {
+  hipLaunchKernelGGL(seed_tick_kernel, dim3(1), dim3(1), 0, s, counter, word);
 }
 int plan_edges_per_thread(int64_t n_edges) { return pick_ept(n_edges); }
 bool fold_node_stat(int64_t n_edges) { return pick_ept(n_edges) == 1; }

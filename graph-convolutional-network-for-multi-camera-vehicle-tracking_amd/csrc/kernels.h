@@ -235,6 +235,7 @@ void launch_pass_c(const RoundParams& p, hipStream_t s);
 // alone (few-edge lists).  avg_degree: edges per source row of THIS call's edges (RoundParams::avg_degree).
 int plan_pass_c(int agg, bool deterministic, bool dropout, int64_t n_edges, int64_t n_nodes, double avg_degree);
 bool pass_c_sorted_taken(int64_t n_nodes);
+void launch_seed_tick(unsigned long long* counter, unsigned long long* word, hipStream_t s);
 int plan_edges_per_thread(int64_t n_edges);      // passes A / B: 1 on few-edge lists, 4 otherwise
 void launch_classify_e0(const EdgeEncParams& enc, const float* attr, int64_t n_edges, double e_total,
                         const float* cls_w, const float* cls_b, int n_classes, float* logits, hipStream_t s);

@@ -82,5 +82,14 @@ void launch_bwd_classify_e0(const EdgeEncParams& enc, const float* attr, int64_t
 void launch_bn_bwd(const BnBwdParams& p, int mode, hipStream_t s);
 void launch_transpose_pad(const float* src, int64_t rows, int cols, int64_t ld_src, float* dst, int64_t rows_pad,
                           hipStream_t s);
+// what the backward accumulates into, cleared by ONE launch: the gaps between the node encoder's weight gradients in the caller's
+// flat gradient buffer (those are plain GEMM outputs) and the workspace's zero range (two memsets, 10.8 MB of them needless, before)
+struct ZeroRanges { int n = 0; struct { uint4* p; size_t n16; } r[MTMC_MAX_ENC_LAYERS + 3]; };
+void launch_zero_ranges(const ZeroRanges& z, hipStream_t s);
+// several padded transposes in one launch (x^T and every W_l^T of the node encoder's backward)
+struct TransposeJob { const float* src; float* dst; int64_t rows, ld_src, rows_pad; int cols; unsigned blocks_r, first_block; };
+struct TransposeJobs { int n = 0; unsigned n_blocks = 0; TransposeJob job[MTMC_MAX_ENC_LAYERS + 1]; };
+void transpose_jobs_add(TransposeJobs& p, const float* src, int64_t rows, int cols, int64_t ld_src, float* dst, int64_t rows_pad);
+void launch_transpose_multi(const TransposeJobs& p, hipStream_t s);
 
 }  // namespace mtmc

@@ -592,6 +592,7 @@ constexpr int kBnBwdRows = 16;   // rows per workgroup: a few hundred node rows 
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p) {
   __shared__ double red[2 * 4 * 64];
+  __shared__ float tile[MODE == 1 ? kBnBwdRows : 1][65];          // MODE 1: dY^T leaves as 16-byte stores, one per thread
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cl;
   const int64_t r0 = (int64_t)blockIdx.y * kBnBwdRows;
@@ -607,7 +608,8 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p) {
 #pragma unroll
     for (int i = 0; i < kBnBwdRows / 4; ++i) {
       const int64_t row = r0 + rg + 4 * i;
-      if (row >= p.rows) break;
+      if (MODE == 1) tile[rg + 4 * i][cl] = 0.f;                  // (rows past the end: the transposed copy's zero padding)
+      if (row >= p.rows) continue;
       const float zh = (p.Y[row * p.dim + col] - mu) * istd;
       const float y = fmaf(gam, zh, bet);
       const bool live = y > 0.f && drop_keep(p.drop, p.drop_stream, (unsigned long long)row * p.dim + col);
@@ -618,17 +620,24 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p) {
       } else {
         const float dy = gam * istd * (g - mg - zh * mgz);
         p.dA[row * p.dim + col] = dy;
-        if (p.dT) p.dT[(int64_t)col * p.ldt + row] = dy;
+        tile[rg + 4 * i][cl] = dy;
         dymax = fmaxf(dymax, fabsf(dy));
         s0 += dy;
       }
     }
   }
-  if (MODE == 1 && p.dT && blockIdx.y == gridDim.y - 1 && col < p.dim)      // the transposed copy's padding rows
-    for (int64_t row = p.rows + rg; row < p.ldt; row += 4) p.dT[(int64_t)col * p.ldt + row] = 0.f;
+  if (MODE == 1 && p.dT && blockIdx.y == gridDim.y - 1 && col < p.dim)      // the transposed copy's padding rows behind the last tile
+    for (int64_t row = r0 + kBnBwdRows + rg; row < p.ldt; row += 4) p.dT[(int64_t)col * p.ldt + row] = 0.f;
   red[rg * 64 + cl] = s0;
   red[256 + rg * 64 + cl] = s1;
   __syncthreads();
+  if (MODE == 1 && p.dT) {
+    static_assert(kBnBwdRows == 16, "a thread stores a quarter of a column's 16 rows");
+    const int c = threadIdx.x >> 2, q = threadIdx.x & 3;
+    if (blockIdx.x * 64 + c < p.dim && r0 + 4 * q < p.ldt)        // (ldt: the row count padded to 32)
+      *reinterpret_cast<float4*>(p.dT + (int64_t)(blockIdx.x * 64 + c) * p.ldt + r0 + 4 * q) =
+          make_float4(tile[4 * q][c], tile[4 * q + 1][c], tile[4 * q + 2][c], tile[4 * q + 3][c]);
+  }
   if (threadIdx.x < 128) {
     const int which = threadIdx.x >> 6, c = blockIdx.x * 64 + (threadIdx.x & 63);
     if (c < p.dim) {
@@ -670,6 +679,30 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* src, in
     const int c = c0 + i;
     const int64_t r = r0 + tx;
     if (c < cols && r < rows_pad) dst[(int64_t)c * rows_pad + r] = tile[tx][i];
+  }
+}
+
+// The same for several matrices in ONE launch (the node encoder's backward needs x^T and every W_l^T, all of them known before
+// its first kernel: four 5 us launches on the chain become one).  1-D grid; a block finds its matrix by the block prefix.
+__global__ __launch_bounds__(256) void transpose_multi_kernel(TransposeJobs p) {
+  __shared__ float tile[32][33];
+  int j = 0;
+  while (j + 1 < p.n && blockIdx.x >= p.job[j + 1].first_block) ++j;
+  const TransposeJob& q = p.job[j];
+  const unsigned b = blockIdx.x - q.first_block;
+  const int64_t r0 = (int64_t)(b % q.blocks_r) * 32;
+  const int c0 = (int)(b / q.blocks_r) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int64_t r = r0 + i;
+    const int c = c0 + tx;
+    tile[i][tx] = (r < q.rows && c < q.cols) ? q.src[r * q.ld_src + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i;
+    const int64_t r = r0 + tx;
+    if (c < q.cols && r < q.rows_pad) q.dst[(int64_t)c * q.rows_pad + r] = tile[tx][i];
   }
 }
 
@@ -786,6 +819,32 @@ void launch_transpose_pad(const float* src, int64_t rows, int cols, int64_t ld_s
                           hipStream_t s) {
   hipLaunchKernelGGL(transpose_pad_kernel, dim3((unsigned)((rows_pad + 31) / 32), (cols + 31) / 32), dim3(256), 0, s,
                      src, rows, cols, ld_src, dst, rows_pad);
+}
+
+__global__ __launch_bounds__(256) void zero_ranges_kernel(ZeroRanges z) {
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int j = 0; j < z.n; ++j)
+    for (size_t i = t0; i < z.r[j].n16; i += nthreads) z.r[j].p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+void launch_zero_ranges(const ZeroRanges& z, hipStream_t s) {
+  size_t total = 0;
+  for (int j = 0; j < z.n; ++j) total += z.r[j].n16;
+  if (total == 0) return;
+  const size_t blocks = (total + 1023) / 1024;                     // four 16-byte stores per thread
+  hipLaunchKernelGGL(zero_ranges_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, s, z);
+}
+
+void transpose_jobs_add(TransposeJobs& p, const float* src, int64_t rows, int cols, int64_t ld_src, float* dst, int64_t rows_pad) {
+  TransposeJob& q = p.job[p.n];
+  q.src = src; q.rows = rows; q.cols = cols; q.ld_src = ld_src; q.dst = dst; q.rows_pad = rows_pad;
+  q.blocks_r = (unsigned)((rows_pad + 31) / 32);
+  q.first_block = p.n_blocks;
+  p.n_blocks += q.blocks_r * (unsigned)((cols + 31) / 32);
+  ++p.n;
+}
+void launch_transpose_multi(const TransposeJobs& p, hipStream_t s) {
+  if (p.n_blocks == 0) return;
+  hipLaunchKernelGGL(transpose_multi_kernel, dim3(p.n_blocks), dim3(256), 0, s, p);
 }
 
 }  // namespace mtmc

@@ -128,6 +128,10 @@ class MOTMPNet(nn.Module):
         # engine.weight_plane_cache): any way of changing a weight -- optimizer steps, `param.data` writes, a new module at the
         # old addresses -- is seen.  False: no cache (few-row graphs then run the split-K kernels of rounds 1-4).
         self.cache_weight_planes = True
+        # Training: None -- every forward draws its Dropout seed from torch's CPU generator (follows torch.manual_seed), a host
+        # value.  An int64 [1] tensor on the model's device -- the seed is read from it ON THE DEVICE and it moves on by one per
+        # forward (MTMC_F_SEED_ON_DEVICE): what a HIP graph of a whole training step needs (capture_training_step sets it).
+        self.device_seed = None
         self._engine = None
 
     # -- the hot path -------------------------------------------------------------------
@@ -165,6 +169,70 @@ class MOTMPNet(nn.Module):
         replay.graph, replay.workspaces = graph, held
         return replay
 
+    def capture_training_step(self, data, loss_fn, optimizer, warmup=3):
+        """Record ONE training step -- `outputs, h = model(data); loss = loss_fn(outputs, h); loss.backward(); optimizer.step()`
+        (reference train.py:356-424) -- into a HIP graph and return `replay() -> loss` (the loss tensor is overwritten by every
+        replay; gradients are written afresh by every replay, as after `zero_grad(set_to_none=True)`).  A config-3 step is ~65
+        kernel launches for 0.6 ms of GPU time: issued one by one the host sets the pace (0.65-0.9 ms from box to box), replayed
+        it is the GPU's time.  Dropout masks change from replay to replay: the seed lives in `self.device_seed`, a device counter
+        the forward reads and advances on the stream (drawn once, here, from torch's generator if it is None).
+        Nothing may still hold an EARLIER step's autograd graph (its loss, its outputs): delete those references first.
+        `warmup` REAL steps run first on the capture stream (lazy setup; the engine's buffers for that stream exist before the
+        capture).  The tensors of `data` (and whatever `loss_fn` closes over) are captured by reference: write the next graph's
+        values of the same shapes into them between replays.  `optimizer` must be capture-safe (e.g. SGD(fused=True)); its
+        hyper-parameters are baked into the graph as plain numbers (a tensor `lr` is read at replay time)."""
+        if not self.training:
+            raise RuntimeError("mtmc_mpn: capture_training_step() is for .train() mode")
+        dev = data.x.device
+        if self.device_seed is None:
+            self.device_seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(dev)    # follows torch.manual_seed
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+
+        def step():
+            outputs, h = self(data)
+            loss = loss_fn(outputs, h)
+            loss.backward()
+            optimizer.step()
+            return loss
+        import gc
+        import warnings
+        gc.collect()
+        warn_always = torch.is_warn_always_enabled()
+        torch.set_warn_always(True)                           # (the warning looked for below is a warn-once one)
+        try:
+            with torch.cuda.stream(side), warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                for _ in range(max(int(warmup), 1)):
+                    optimizer.zero_grad(set_to_none=True)
+                    step()
+            side.synchronize()
+        finally:
+            torch.set_warn_always(warn_always)
+        for w in caught:
+            if "AccumulateGrad node's stream does not match" in str(w.message):
+                # gradient-accumulation nodes of an EARLIER step on another stream are still alive (something still holds that
+                # step's autograd graph: its loss or outputs).  They would run on that stream during the capture and break it
+                # (on this ROCm build: a crash, not an exception) -- refuse before trying.
+                raise RuntimeError("mtmc_mpn.capture_training_step: an earlier step's autograd graph is still alive (its loss or "
+                                   "outputs are referenced somewhere): delete those references (`del loss, outputs`) and call again")
+            warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+        optimizer.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            loss = step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        from . import torch_ops
+        eng = torch_ops.engine_for(self._config_key)
+        key = (dev, side.cuda_stream)
+        held = [buf for buf in (eng._ws.pop(key, None), eng._wc.pop(key, None)) if buf is not None] + [side]
+
+        def replay():
+            graph.replay()
+            return loss
+        replay.graph, replay.workspaces = graph, held
+        return replay
+
     def forward(self, data):
         """`outputs, latent_node_feats = mpn_model(data)` (reference inference.py:469, train.py:356): one call of the
         registered op `torch.ops.mtmc_mpn.mp_forward`; under grad mode / `.train()` it records the tape its autograd
@@ -184,13 +252,20 @@ class MOTMPNet(nn.Module):
         needs_grad = torch.is_grad_enabled() and (
             x.requires_grad or edge_attr.requires_grad or any(p.requires_grad for p in params))
         tape = bool(needs_grad or self.training)
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if self.training else 0    # follows torch.manual_seed
         flags = (_lib_flags.F_DETERMINISTIC if self.deterministic else 0) | \
             (torch_ops.CHECK_INDICES if self.check_indices else 0) | \
             (0 if self.cache_weight_planes else torch_ops.NO_WEIGHT_CACHE)
+        if self.training and self.device_seed is not None:
+            ds = self.device_seed
+            if not (isinstance(ds, torch.Tensor) and ds.dtype == torch.int64 and ds.numel() == 1 and ds.device == x.device):
+                raise RuntimeError("mtmc_mpn: device_seed must be an int64 tensor of one element on the device of data.x")
+            seed, flags = ds.data_ptr(), flags | _lib_flags.F_SEED_ON_DEVICE
+        else:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if self.training else 0    # follows torch.manual_seed
         if tape and edge_index.is_cuda and edge_attr.is_cuda and not torch.compiler.is_compiling():
             # grad mode: the op's own forward / backward functions without the dispatcher around them (torch_ops._MpForwardLean)
-            logits, h = torch_ops.mp_forward_lean(x, edge_index, edge_attr, params, self._config_key, self.training, seed, flags)
+            steps, h = torch_ops.mp_forward_lean(x, edge_index, edge_attr, params, self._config_key, self.training, seed, flags)
+            return {"classified_edges": steps}, h
         else:
             logits, h, _ = torch.ops.mtmc_mpn.mp_forward(x, edge_index, edge_attr, params, self._config_key,
                                                          self.training, seed, flags, tape)

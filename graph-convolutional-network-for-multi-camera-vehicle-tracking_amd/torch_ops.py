@@ -152,8 +152,9 @@ def _mp_forward_fake(x, edge_index, edge_attr, params, config, training, seed, f
 
 
 def _mp_backward(tape, x, edge_index, edge_attr, params, config, training, seed, flags, d_logits, d_h, need_x, need_attr,
-                 prep=None):
-    """prep: the forward's prepared call (the lean autograd path keeps it: same tensors, same structs); None: rebuilt."""
+                 prep=None, d_steps=None):
+    """prep: the forward's prepared call (the lean autograd path keeps it: same tensors, same structs); None: rebuilt.
+    d_steps: the gradients of the classified steps as separate [E, C] tensors (None entries: no gradient), instead of d_logits."""
     eng = engine_for(config)
     eng.flags = int(flags) & 0xFFFF
     spec = eng.spec
@@ -170,8 +171,12 @@ def _mp_backward(tape, x, edge_index, edge_attr, params, config, training, seed,
     dh = d_h.contiguous().float() if d_h is not None else None
     n_steps = _n_out(spec)
     step_bytes = 4 * prep.e * spec.cls_edge[0].out_dim
-    steps = (C.c_void_p * max(n_steps, 1))(*[(dl.data_ptr() + i * step_bytes) if dl is not None and dl.numel() else None
-                                             for i in range(n_steps)])
+    if d_steps is not None:
+        d_steps = [t.contiguous().float() if t is not None and t.numel() else None for t in d_steps]   # (kept alive to the call)
+        steps = (C.c_void_p * max(n_steps, 1))(*[t.data_ptr() if t is not None else None for t in d_steps])
+    else:
+        steps = (C.c_void_p * max(n_steps, 1))(*[(dl.data_ptr() + i * step_bytes) if dl is not None and dl.numel() else None
+                                                 for i in range(n_steps)])
     with torch.cuda.device(dev):
         prep.call.stream = _stream(dev)
         _lib.check(eng.lib.mtmc_mpn_backward_flat(
@@ -246,18 +251,24 @@ class _MpForwardLean(torch.autograd.Function):
         ctx.structs = (prep.model, prep.call, prep.n, prep.e, prep.dev)
         ctx.n_keep = len(prep.keep)
         ctx.save_for_backward(prep.ws, *prep.keep, *params)
-        return prep.logits, prep.h
+        # One output per classified step (consecutive [E, C] slices of one block, which is what ops.cross_entropy_steps looks
+        # for): the loss hands back one gradient per step and the library takes them as they are -- `logits.unbind(0)` outside
+        # would make autograd stack them again (a 4 MB copy kernel per step at config 3).  An output nobody used (h, in every
+        # training loop of the reference) gets None, not a zero-filled tensor.
+        ctx.set_materialize_grads(False)
+        return (*prep.logits.unbind(0), prep.h)
 
     @staticmethod
-    def backward(ctx, d_logits, d_h):
+    def backward(ctx, *d_out):
         import types
+        d_steps, d_h = d_out[:-1], d_out[-1]
         ws, *rest = ctx.saved_tensors
         keep, params = rest[:ctx.n_keep], rest[ctx.n_keep:]
         model, call, n, e, dev = ctx.structs
         prep = types.SimpleNamespace(model=model, call=call, ws=ws, n=n, e=e, dev=dev, keep=tuple(keep))
         x, edge_index, edge_attr = keep[0], keep[1], keep[2]
         flat, dx, dattr = _mp_backward(ws, x, edge_index, edge_attr, params, ctx.config, ctx.training, ctx.seed, ctx.flags,
-                                       d_logits, d_h, ctx.need_x, ctx.need_attr, prep=prep)
+                                       None, d_h, ctx.need_x, ctx.need_attr, prep=prep, d_steps=d_steps)
         spec = engine_for(ctx.config).spec
         layout, _ = grad_layout(spec)
         grads = [flat[o:o + n].view(shp) for o, n, shp in layout]
@@ -272,8 +283,9 @@ class _MpForwardLean(torch.autograd.Function):
 
 
 def mp_forward_lean(x, edge_index, edge_attr, params, config, training, seed, flags):
-    """(logits [S,E,C], h [N,32]) with autograd, for CUDA tensors: see _MpForwardLean."""
-    return _MpForwardLean.apply(x, edge_index, edge_attr, config, training, seed, flags, *params)
+    """([logits_step [E,C], ...], h [N,32]) with autograd, for CUDA tensors: see _MpForwardLean."""
+    *steps, h = _MpForwardLean.apply(x, edge_index, edge_attr, config, training, seed, flags, *params)
+    return steps, h
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -132,6 +132,12 @@ typedef struct mtmc_mpn_call {
  * cache verifies itself, mtmc_mpn_call::weight_cache.) */
 #define MTMC_F_FORK 2            /* run the edge branch (prep, edge-encoder moments) on an internal side stream
                                     beside the node-encoder GEMMs, joined by events (default: one stream) */
+#define MTMC_F_SEED_ON_DEVICE 16 /* training: `seed` holds the ADDRESS of a uint64 counter in device memory (8-byte aligned).  The
+                                    forward takes the counter's value as this call's Dropout seed, stores it in the workspace
+                                    (= the tape: the backward of the same tape reads it there) and moves the counter on by one --
+                                    on the stream, so a HIP graph that holds a whole training step (forward, loss, backward,
+                                    optimizer) draws new masks on every replay.  Additive in ABI v6: calls without the bit are
+                                    as before (`seed` by value).  Reference: nn.Dropout's generator state, models/mlp.py:20-21 */
 
 /* Byte offsets inside the workspace of the regions a multi-GPU host exchanges between phases.
  * Every statistics block is kept in MTMC_STAT_REPLICAS replicas (consumers add them up), so a host simply

@@ -10,4 +10,4 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 r = bench.run_training_step(torch.device("cuda:0"))
-print(json.dumps({k: r[k] for k in ("ms_per_step", "step_ms_gpu_side", "step_ms_host_issue")}))
+print(json.dumps({k: r.get(k) for k in ("ms_per_step", "launch", "ms_per_step_eager", "graph_replay", "step_ms_gpu_side", "step_ms_host_issue")}))
