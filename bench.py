@@ -37,6 +37,8 @@ PHASE_NAMES = {_lib.PH_BEGIN: "memset+prep_kernel(+split_rows_kernel)", _lib.PH_
                _lib.PH_ROUND_A: "pass_a_kernel", _lib.PH_ROUND_B: "pass_b_kernel", _lib.PH_ROUND_STAT: "node_stat_kernel",
                _lib.PH_ROUND_C: "pass_c_kernel", _lib.PH_END: "h_final_kernel"}
 
+SMALL_EDGES = 6144 * 256        # csrc/kernels.h kSmallEdges: the few-edge forms of the edge passes up to here
+
 WORKLOADS = {
     # name: (description, L, Cs)
     "s02": ("AIC19-S02 ground-truth topology, cams 124/90/99/137: N=450 E=150454", 3, 1),
@@ -150,7 +152,7 @@ def phase_cost(ph, arg, spec, n, e):
         _lib.PH_NODE_H0: 256 * n,
         _lib.PH_ROUND_PROJ: (128 + 32 + 128 + 128 + 4) * n,            # h in, P, Q out, cleared aggregation buffer, degree
         _lib.PH_ROUND_A: (8 + e_in + 16) * e + 32 * n,                 # row/col + e_in read, z1 written, P table once
-        _lib.PH_ROUND_B: (4 + 16 + (0 if e > 2048 * 256 else 16)) * e + (32 if e > 2048 * 256 else 128) * n,   # row + z1 read; segment sums, or (few-edge graphs) e' written + one Q row per run
+        _lib.PH_ROUND_B: (4 + 16 + (0 if e > SMALL_EDGES else 16)) * e + (32 if e > SMALL_EDGES else 128) * n,   # row + z1 read; segment sums, or (few-edge graphs) e' written + one Q row per run
         _lib.PH_ROUND_STAT: (128 + 4 + 32) * n,
         _lib.PH_ROUND_C: (4 + 16) * e + (128 + 128) * n + (8 * e if arg >= spec.num_enc_steps - spec.num_class_steps else 0),
         _lib.PH_END: 256 * n,
@@ -243,7 +245,7 @@ def time_phases(model, data, iters):
             if it >= 2:
                 for i, (a, b) in enumerate(evs):
                     sums[i] += a.elapsed_time(b)
-    folded = data.edge_index.shape[1] <= 2048 * 256
+    folded = data.edge_index.shape[1] <= SMALL_EDGES
     keep = [i for i, (ph, _) in enumerate(seq) if not (folded and ph == _lib.PH_ROUND_STAT)]
     return [seq[i] for i in keep], [sums[i] / iters for i in keep]
 

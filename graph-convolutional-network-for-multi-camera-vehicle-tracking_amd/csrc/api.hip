@@ -193,10 +193,10 @@ int32_t mtmc_mpn_plan_call(const mtmc_mpn_model* model, const mtmc_mpn_call* cal
     const bool big_last = (last == 0 && pre0) ||
                           (last >= 1 && !c->training && ((mtmc::staged_layer(c->n_nodes, L.in_dim, L.out_dim) && mtmc::staged_layer(rows, L.in_dim, L.out_dim)) ||
                                                          (mtmc::rows_layer(c->n_nodes, L.in_dim, L.out_dim) && mtmc::rows_layer(rows, L.in_dim, L.out_dim))));
-    out->enc2_passenger = (c->n_edges > 0 && rows > 0 && c->n_edges <= (int64_t)2048 * 256 && !big_last &&
+    out->enc2_passenger = (c->n_edges > 0 && rows > 0 && c->n_edges <= mtmc::kSmallEdges && !big_last &&
                            mtmc::gemm_plan(rows, L.in_dim, L.out_dim, &sk) == 1 && !(c->flags & MTMC_F_FORK)) ? 1 : 0;
     if (few)
-      out->enc2_passenger = (c->n_edges > 0 && c->n_edges <= (int64_t)2048 * 256 && last >= 1 &&
+      out->enc2_passenger = (c->n_edges > 0 && c->n_edges <= mtmc::kSmallEdges && last >= 1 &&
                              mtmc::few_wave_threads(L.in_dim) == 256 && !(c->flags & MTMC_F_FORK)) ? 1 : 0;
   }
   return MTMC_OK;

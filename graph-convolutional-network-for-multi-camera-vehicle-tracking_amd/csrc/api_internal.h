@@ -346,7 +346,7 @@ inline double avg_degree(const mtmc_mpn_call* c) {
   return c->n_nodes > 0 ? (double)c->n_edges_total / (double)c->n_nodes : 0.0;
 }
 // eval mode, many local edges: e' is never stored (passes B/C and the next round's pass A recompute it from z1)
-inline bool lazy_edges(const mtmc_mpn_call* c) { return !c->training && c->n_edges > 2048 * 256; }
+inline bool lazy_edges(const mtmc_mpn_call* c) { return !c->training && c->n_edges > mtmc::kSmallEdges; }
 
 // column blocks of this call's pass A: the layout has the index (table size, edge count) AND the call's own degree pays
 inline int call_col_blocks(const Ctx& x) {
@@ -449,7 +449,7 @@ inline int l0_panels(int64_t rows, int Nout, int64_t* cuts, int* bm) {
 inline bool enc2_can_ride(const Ctx& x) {
   const int last = x.m->n_enc_layers - 1;
   const int64_t rows = x.c->node_hi - x.c->node_lo;
-  if (x.c->n_edges <= 0 || rows <= 0 || x.c->n_edges > (int64_t)2048 * 256) return false;
+  if (x.c->n_edges <= 0 || rows <= 0 || x.c->n_edges > mtmc::kSmallEdges) return false;
   if (use_few(x)) return last >= 1 && mtmc::few_wave_threads(x.m->enc_node[last].in_dim) == 256;   // (enc2_body: 256 threads)
   if ((last == 0 && use_presplit0(x)) || use_staged(x, last) || use_rows(x, last)) return false;
   int sk;

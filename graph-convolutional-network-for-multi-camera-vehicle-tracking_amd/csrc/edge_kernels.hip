@@ -1521,14 +1521,16 @@ __global__ __launch_bounds__(256) void classify_e0_kernel(EdgeEncParams enc, con
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
+#ifndef MTMC_EDGE_GRID_CAP
+#define MTMC_EDGE_GRID_CAP 2048
+#endif
 static inline int edge_grid(int64_t n_edges, int per_block) {
   const int64_t blocks = (n_edges + per_block - 1) / per_block;
-  return (int)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
+  return (int)(blocks < 1 ? 1 : (blocks > MTMC_EDGE_GRID_CAP ? MTMC_EDGE_GRID_CAP : blocks));
 }
 
-// Below this many edges a pass at 4 edges/thread would leave most of the 256 CUs with one or two waves: use the
-// finest decomposition there (measured on camera graphs of 50k..12M edges, tools/size_sweep.py).
-constexpr int64_t kSmallEdges = 2048 * 256;
+// Below kSmallEdges (kernels.h) a pass at 4 edges/thread would leave most of the 256 CUs with one or two waves: use the
+// finest decomposition there (measured on camera graphs of 50k..12M edges, tools/size_sweep.py, tools/regime_sweep.py).
 constexpr int64_t kSortedMaxNodes = 1ll << 24;   // pass_c_sorted_kernel keeps row ids in 24 bits
 static inline int pick_ept(int64_t n_edges) { return n_edges <= kSmallEdges ? 1 : 4; }
 #ifndef MTMC_PASS_A_EPT
@@ -1654,7 +1656,8 @@ int plan_pass_c(int agg, bool deterministic, bool dropout, int64_t n_edges, int6
   // (MTMC_PASS_C_GENERAL, or >= 2^24 GLOBAL node rows, reachable with row-sharded multi-GPU calls): that one only knows
   // float atomics, so a deterministic call keeps the walk there (its carry[] is what agg_fixup_kernel adds up)
   if (n_edges > kSmallEdges) return (deterministic && (kn.pass_c_general || n_nodes >= kSortedMaxNodes)) ? 0 : 1;
-  if (deterministic) return 0;                               // few edges: fixed-order sums live in the walk
+  if (deterministic)                                         // fixed-order sums: the sorted kernel's DET form where it pays, else the walk
+    return (n_edges > kDetSortedEdges && !kn.pass_c_general && n_nodes < kSortedMaxNodes) ? 1 : 0;
   return n_edges >= kn.pass_c_small_min ? 2 : 0;
 }
 void launch_seed_tick(unsigned long long* counter, unsigned long long* word, hipStream_t s) {

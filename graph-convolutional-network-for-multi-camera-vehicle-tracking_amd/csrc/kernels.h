@@ -235,6 +235,17 @@ void launch_pass_c(const RoundParams& p, hipStream_t s);
 // alone (few-edge lists).  avg_degree: edges per source row of THIS call's edges (RoundParams::avg_degree).
 int plan_pass_c(int agg, bool deterministic, bool dropout, int64_t n_edges, int64_t n_nodes, double avg_degree);
 bool pass_c_sorted_taken(int64_t n_nodes);
+// Few-edge / many-edge regime of the edge passes (edge_kernels.hip: pick_ept).  Up to this many edges: one edge per thread in
+// passes A / B, e' stored, the node-update statistics folded into node_proj + pass B, ONE any-order matrix-core pass C, the
+// operand-split jobs and enc2 as passengers; above: four edges per thread, lazy e', node_stat, pass_c_sorted + the walk behind
+// it.  Rounds 1-4: 2048 * 256 (one 2048-block grid of one edge per thread); round 5, after the few-edge forms lost three
+// launches per round: 4-camera graphs of 0.75 / 1.08 / 1.47 / 1.92 / 3.0 M edges take 204 / 252 / 288 / 342 / 448 us with the
+// few-edge forms and 223 / 252 / 296 / 315 / 375 us with the many-edge ones (profiles/r05_regime_sweep.txt): 6144 * 256.
+#ifndef MTMC_SMALL_EDGES
+#define MTMC_SMALL_EDGES (6144 * 256)
+#endif
+constexpr int64_t kSmallEdges = MTMC_SMALL_EDGES;
+constexpr int64_t kDetSortedEdges = 2048 * 256;      // deterministic mode keeps pass_c_sorted_kernel<., true> from here up
 void launch_seed_tick(unsigned long long* counter, unsigned long long* word, hipStream_t s);
 int plan_edges_per_thread(int64_t n_edges);      // passes A / B: 1 on few-edge lists, 4 otherwise
 void launch_classify_e0(const EdgeEncParams& enc, const float* attr, int64_t n_edges, double e_total,

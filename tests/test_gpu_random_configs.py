@@ -1,6 +1,7 @@
 """Seeded random sweep over the configuration family (L, Cs, aggregation, reattach flags, edge feature width, graph
 shape and edge order) against the fp64 oracle: catches interactions the named fixtures do not pair up."""
 import copy
+import os
 import types
 
 import pytest
@@ -20,7 +21,9 @@ def _case(seed):
     over = dict(num_enc_steps=r(0, 3), num_class_steps=r(1, 3), node_agg_fn=["sum", "mean", "max"][r(0, 2)],
                 reattach_initial_nodes=bool(r(0, 1)), reattach_initial_edges=bool(r(0, 1)))
     kind = r(0, 2)
-    if kind == 0:
+    if seed >= 16 and seed % 4 == 0:                         # (extended sweeps: both sides of the few-row threshold, 1536 rows)
+        d = graphs.random_graph(r(1400, 1700), r(2000, 40000), 2048, seed=seed)
+    elif kind == 0:
         d = graphs.random_graph(r(8, 300), r(16, 4000), 2048, seed=seed)
     else:
         cams = [r(3, 60) for _ in range(r(2, 5))]
@@ -31,7 +34,8 @@ def _case(seed):
     return over, d
 
 
-@pytest.mark.parametrize("seed", range(16))
+# MTMC_FUZZ_SEEDS=400 python -m pytest tests/test_gpu_random_configs.py : a longer sweep (tools/r05_24.sh ran 400 / 60 in round 5)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MTMC_FUZZ_SEEDS", "16"))))
 def test_random_configuration(seed):
     over, d = _case(seed)
     params = mtmc_mpn.default_params(**over)
@@ -41,7 +45,10 @@ def test_random_configuration(seed):
     with torch.no_grad():
         want, want_h = mpn_oracle.forward(sd, copy.deepcopy(params), ARCH, d.x, d.edge_index, d.edge_attr, dtype=torch.float64)
         m = m.cuda()
-        out, h = m(types.SimpleNamespace(x=d.x.cuda(), edge_index=d.edge_index.cuda(), edge_attr=d.edge_attr.cuda()))
+        data = types.SimpleNamespace(x=d.x.cuda(), edge_index=d.edge_index.cuda(), edge_attr=d.edge_attr.cuda())
+        out, h = m(data)
+        if seed & 1:                                          # the second forward reads verified planes from the weight cache
+            out, h = m(data)
     assert len(out["classified_edges"]) == len(want["classified_edges"]), over
     for a, b in zip(out["classified_edges"], want["classified_edges"]):
         assert (a.cpu().double() - b).abs().max().item() <= 1e-4, (over, d.x.shape, d.edge_index.shape)

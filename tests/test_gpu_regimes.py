@@ -2,11 +2,13 @@
 
 The tracker-scale S02 graph -- cams 250/221/281/250 (the reference's misc/mtsc_BUPT21 counts for c007/c008, 250 for the
 two cameras whose files are not shipped) in ONE graph, as `bs_test = 2000` makes it (main.py:86, inference.py:407-413):
-N = 1002, E = 751 202 -- is the one place where FEW node rows (64x64-tile, split-K encoder plan) meet MANY edges
-(> 524 288: four edges per thread in passes A/B, e' never stored, the matrix-core pass C with the walk launched behind it).
-On top of it, the same graph
-  * with a seeded edge permutation: rows unsorted above 524 288 edges -> the matrix-core kernel returns at once on the
-    device-side flag and the half-wave walk does every round;
+N = 1002, E = 751 202 -- is the largest list the FEW-edge forms of the edge passes take since round 5 (<= 1 572 864 edges: one edge
+per thread in grid-stride loops, e' stored, ONE any-order matrix-core pass C); a second graph of the same kind, four cameras of
+370 tracklets (N = 1480, E = 1 642 800), is where FEW node rows (the few-row encoder kernels) meet the MANY-edge forms (four edges
+per thread in passes A/B, e' never stored, the sorted matrix-core pass C with the walk launched behind it).
+On top of both, the same graphs
+  * with a seeded edge permutation: rows unsorted -> above the threshold the sorted matrix-core kernel returns at once on the
+    device-side flag and the half-wave walk does every round; below it the any-order kernel takes masked passes / per-edge atomics;
   * with nodes interleaved over the cameras, i.e. the TRAINING order (train.py:295-302, :323-329): rows sorted inside
     each camera block only;
   * in deterministic mode (fixed-order aggregation; bitwise repeatable h).
@@ -39,12 +41,27 @@ def _build(cam_of_node=None, seed=2):
     return types.SimpleNamespace(x=x, edge_index=ei, edge_attr=ea)
 
 
+SMALL_EDGES = 6144 * 256          # csrc/kernels.h kSmallEdges: the few-edge forms of the edge passes up to here
+
+
 @pytest.fixture(scope="module")
 def tracker():
     d = _build()
     assert d.x.shape[0] == 1002 and d.edge_index.shape[1] == 751_202
     assert bool((d.edge_index[0][1:] >= d.edge_index[0][:-1]).all())       # inference order: rows non-decreasing
     return d
+
+
+@pytest.fixture(scope="module")
+def many_edge():
+    d = _build(cam_of_node=torch.repeat_interleave(torch.arange(4), torch.tensor([370] * 4)), seed=3)
+    assert d.x.shape[0] == 1480 and d.edge_index.shape[1] == 1_642_800 > SMALL_EDGES
+    return d
+
+
+@pytest.fixture(params=["tracker", "many_edge"])
+def big(request):
+    return request.getfixturevalue(request.param)
 
 
 def _model(L, Cs=1, **over):
@@ -87,8 +104,8 @@ def test_tracker_scale_s02_against_fp64_oracle(tracker, L, Cs):
     """SURVEY 8(d) config 2b at the shipped L = 1 and at the metric's L = 3 (and every step classified)."""
     m, sd, params = _model(L, Cs)
     plan = engine.ForwardEngine(m).plan(1002, 751_202)
-    assert plan.pass_c == _lib.PASS_C_MFMA_SORTED and plan.lazy_edges and plan.edges_per_thread == 4
-    assert plan.enc_kernel[0] == _lib.GEMM_FEW_L0 and plan.enc_kernel[1] == _lib.GEMM_FEW_WAVE   # the regime this test is for
+    assert plan.pass_c == _lib.PASS_C_MFMA_ANY and not plan.lazy_edges and plan.edges_per_thread == 1     # few-edge forms, in
+    assert plan.enc_kernel[0] == _lib.GEMM_FEW_L0 and plan.enc_kernel[1] == _lib.GEMM_FEW_WAVE            # grid-stride loops
     got, h = _gpu(m.cuda(), tracker)
     want64, h64 = _oracle(sd, params, tracker)
     assert len(got) == Cs
@@ -100,11 +117,24 @@ def test_tracker_scale_s02_against_fp64_oracle(tracker, L, Cs):
     assert err <= max(4 * ref_err, 2e-5), f"|gpu - fp64| {err:.2e} vs the fp32 reference's own {ref_err:.2e}"
 
 
+def test_many_edge_forms_meet_the_few_row_encoder(many_edge):
+    """1480 rows / 1 642 800 edges at the metric's L = 3: the few-row encoder kernels with the many-edge edge passes."""
+    m, sd, params = _model(3, 1)
+    plan = engine.ForwardEngine(m).plan(1480, 1_642_800)
+    assert plan.pass_c == _lib.PASS_C_MFMA_SORTED and plan.lazy_edges and plan.edges_per_thread == 4
+    assert plan.enc_kernel[0] == _lib.GEMM_FEW_L0 and plan.enc_kernel[1] == _lib.GEMM_FEW_WAVE
+    got, h = _gpu(m.cuda(), many_edge)
+    want64, h64 = _oracle(sd, params, many_edge)
+    _check(got, h, want64, h64, "1480 / 1642800 L=3")
+
+
 @pytest.mark.parametrize("agg", ["sum", "mean"])
-def test_unsorted_rows_above_524288_edges(tracker, agg):
-    """A seeded permutation of the 751 202 edges: prep_kernel flags the rows as unsorted, pass_c_mfma_kernel returns at
-    once and pass_c_kernel (the walk, atomics per short run) does every round.  Logits must match the sorted run's after
-    un-permuting (G7's property, at a size that takes the many-edge kernels) and the oracle on the permuted list."""
+def test_unsorted_rows_of_long_lists(big, agg):
+    """A seeded permutation of the edges.  Above the regime threshold prep_kernel flags the rows as unsorted, the sorted
+    matrix-core kernel returns at once and pass_c_kernel (the walk, atomics per short run) does every round; below it the
+    any-order matrix-core kernel takes the list as it comes.  Logits must match the sorted run's after un-permuting (G7's
+    property, at these sizes) and the oracle on the permuted list."""
+    tracker = big
     m, sd, params = _model(3, 1, node_agg_fn=agg)
     m = m.cuda()
     sorted_logits, sorted_h = _gpu(m, tracker)
@@ -121,24 +151,25 @@ def test_unsorted_rows_above_524288_edges(tracker, agg):
 def test_training_order_rows_block_sorted_at_tracker_scale():
     """Nodes ordered by identity, cameras interleaved (train.py:295-302): the edge list is a concatenation of per-camera
     blocks (train.py:323-329), rows ascending inside a block only -- unsorted for the kernels, with long sorted runs."""
-    cam = torch.arange(1002) % 4
+    cam = torch.arange(1480) % 4
     d = _build(cam_of_node=cam, seed=7)
     row = d.edge_index[0]
-    assert d.edge_index.shape[1] > 524_288 and not bool((row[1:] >= row[:-1]).all())
+    assert d.edge_index.shape[1] > SMALL_EDGES and not bool((row[1:] >= row[:-1]).all())
     m, sd, params = _model(3, 3)
     got, h = _gpu(m.cuda(), d)
     want64, h64 = _oracle(sd, params, d)
     _check(got, h, want64, h64, "training order")
 
 
-def test_deterministic_mode_above_524288_edges(tracker):
-    """MTMC_F_DETERMINISTIC on a many-edge sorted list: per-span partials + agg_fixup_kernel instead of float atomics, on the
-    matrix-core kernel (pass_c_sorted_kernel<., true>; E % 64 = 34: the partial last chunk is its own, too).
-    h and the logits must be BITWISE equal between runs, and right."""
+def test_deterministic_mode_above_524288_edges(big):
+    """MTMC_F_DETERMINISTIC on a long sorted list: per-span partials + agg_fixup_kernel instead of float atomics, on the
+    matrix-core kernel (pass_c_sorted_kernel<., true>; 751 202 % 64 = 34: the partial last chunk is its own, too) -- with e'
+    stored (751 202 edges) and recomputed (1 642 800).  h and the logits must be BITWISE equal between runs, and right."""
+    tracker = big
     m, sd, params = _model(3, 1)
     m = m.cuda()
     m.deterministic = True
-    assert engine.ForwardEngine(m).plan(1002, 751_202, flags=_lib.F_DETERMINISTIC).pass_c == _lib.PASS_C_MFMA_SORTED
+    assert engine.ForwardEngine(m).plan(tracker.x.shape[0], tracker.edge_index.shape[1], flags=_lib.F_DETERMINISTIC).pass_c == _lib.PASS_C_MFMA_SORTED
     got1, h1 = _gpu(m, tracker)
     got2, h2 = _gpu(m, tracker)
     assert torch.equal(h1, h2) and torch.equal(got1[0], got2[0])
@@ -149,8 +180,9 @@ def test_deterministic_mode_above_524288_edges(tracker):
     assert (h3 - h1).abs().max().item() <= 1e-5 * max(1.0, h1.abs().max().item())
 
 
-def test_max_aggregation_and_reattach_at_tracker_scale(tracker):
-    """The variants that stay on the walk / the MODE 2-3 pass A, at a many-edge size (fixtures cover them at <= 150k)."""
+def test_max_aggregation_and_reattach_at_tracker_scale(big):
+    """The variants that stay on the walk / the MODE 2-3 pass A, at long-list sizes (fixtures cover them at <= 150k)."""
+    tracker = big
     for over in (dict(node_agg_fn="max"), dict(reattach_initial_edges=True, reattach_initial_nodes=True)):
         m, sd, params = _model(2, 2, **over)
         got, h = _gpu(m.cuda(), tracker)
@@ -160,7 +192,7 @@ def test_max_aggregation_and_reattach_at_tracker_scale(tracker):
 
 # ---- both sides of every dispatch threshold -----------------------------------------------------------------------------
 # The library switches kernels at: 4096 node rows (pre-split layer 0, role-split layer 1, row-streaming layer 3 vs the in-loop
-# kernel), 49 152 node rows (role-split layer 2 with 256-row tiles), 524 288
+# kernel), 49 152 node rows (role-split layer 2 with 256-row tiles), 1 572 864
 # edges (edges per thread, lazy e', which pass-C combination), 32 768 edges and 24 edges per source row (matrix-core pass C
 # or the walk).  A graph just below and just above each of them must give the oracle's answer, and the plan query must
 # say the two sides really take different kernels (otherwise the test tests nothing).
@@ -175,7 +207,7 @@ THRESHOLDS = [
     ("1536 node rows", (1500, 30_000), (1600, 30_000), "enc_kernel"),
     ("4096 node rows", (4000, 60_000), (4200, 60_000), "enc_kernel"),
     ("49152 node rows", (49_000, 150_000), (49_300, 150_000), "enc_kernel"),
-    ("524288 edges", (3000, 255_000), (3000, 270_000), "edges_per_thread"),
+    ("1572864 edges", (3000, 780_000), (3000, 792_000), "edges_per_thread"),
     ("32768 edges", (500, 15_000), (500, 18_000), "pass_c"),
     ("24 edges per source row", (2000, 22_000), (2000, 26_000), "pass_c"),
 ]
@@ -250,7 +282,7 @@ def test_many_node_variants(over):
 
 # ---- the sorted-list matrix-core pass C (pass_c_sorted_kernel) on lists whose 32-edge groups are NOT one or two rows ------
 def _mixed_degree_graph(n_dense, pairs_dense, n_sparse, pairs_sparse, seed, drop_tail=0):
-    """Row-sorted list of > 524 288 edges: a dense block of nodes (hundreds of edges per row: one- and two-row groups) followed
+    """Row-sorted list of > 524 288 (270 000 dense pairs) or > 1 572 864 edges (800 000): a dense block of nodes (hundreds of edges per row: one- and two-row groups) followed
     by a sparse block (a handful of edges per row: groups of 3-4 rows take the masked passes, groups of more rows the
     per-register atomics), and isolated nodes in between.  drop_tail trims the list so that E % 64 takes a chosen value."""
     g = torch.Generator().manual_seed(seed)
@@ -299,13 +331,13 @@ def test_deterministic_sorted_list_with_low_degree_stretches(tail):
 
 @pytest.mark.parametrize("tail", [0, 1, 37])
 def test_sorted_many_edge_list_with_low_degree_stretches(tail):
-    d = _mixed_degree_graph(1500, 270_000, 6000, 9_000, seed=77)
+    d = _mixed_degree_graph(1500, 800_000, 6000, 9_000, seed=77)
     E = d.edge_index.shape[1]
     drop = (E - tail) % 64                                   # leave exactly `tail` edges behind the last whole 64-edge chunk
     if drop:
         d = types.SimpleNamespace(x=d.x, edge_index=d.edge_index[:, :E - drop].contiguous(), edge_attr=d.edge_attr[:E - drop].contiguous())
     E = d.edge_index.shape[1]
-    assert E > 524_288 and E % 64 == tail
+    assert E > SMALL_EDGES and E % 64 == tail
     m, sd, params = _model(2, 2)
     plan = engine.ForwardEngine(m).plan(d.x.shape[0], E)
     assert plan.pass_c == _lib.PASS_C_MFMA_SORTED, plan.pass_c

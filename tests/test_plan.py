@@ -61,7 +61,8 @@ def test_single_gpu_regimes(eng):
     old = eng.plan(450, 150_454, weight_cache=False)   # ... without one (plain C callers, cache_weight_planes = False): rounds 1-4
     assert old.enc_kernel == [_lib.GEMM_INLOOP_64] * 4 and old.enc_split_k[:3] == [4, 4, 4] and old.enc_split_k[3] == 1
     assert old.enc2_passenger and s02.enc2_passenger
-    trk = eng.plan(1002, 751_202)                      # few rows AND more than 524288 edges
+    trk = eng.plan(1002, 751_202)                      # since round 5 on the few-edge forms (<= 1572864 edges)
+    big = eng.plan(1480, 1_642_800)                    # four cameras of 370: few rows AND the many-edge forms
     assert trk.enc_kernel == [_lib.GEMM_FEW_L0] + [_lib.GEMM_FEW_WAVE] * 3
     trk_old = eng.plan(1002, 751_202, weight_cache=False)
     assert trk_old.enc_kernel == [_lib.GEMM_INLOOP_64] * 4 and trk_old.enc_split_k == [1, 4, 4, 1]   # 256 tiles in layer 0: unsplit
@@ -69,7 +70,9 @@ def test_single_gpu_regimes(eng):
     assert mid.enc_kernel == [_lib.GEMM_INLOOP_64] * 4
     shard = eng.plan(450, 75_000, 150_454, node_range=(0, 225))    # a rank of a 2-way split of the headline graph
     assert shard.enc_kernel == s02.enc_kernel
-    assert trk.pass_c == _lib.PASS_C_MFMA_SORTED and trk.lazy_edges and trk.edges_per_thread == 4
+    assert trk.pass_c == _lib.PASS_C_MFMA_ANY and not trk.lazy_edges and trk.edges_per_thread == 1
+    assert big.enc_kernel == trk.enc_kernel
+    assert big.pass_c == _lib.PASS_C_MFMA_SORTED and big.lazy_edges and big.edges_per_thread == 4
     cfg4 = eng.plan(100_000, 10_000_000)
     assert cfg4.enc_kernel[0] == _lib.GEMM_PRESPLIT_256 and cfg4.pass_c == _lib.PASS_C_MFMA_SORTED
     assert cfg4.pass_a_col_blocks == 0 and s02.pass_a_col_blocks == 0      # 1.6 MB of Pc fit an XCD's L2: edge order
@@ -77,7 +80,8 @@ def test_single_gpu_regimes(eng):
     # the many-row graphs' pipelined layer 0 (3 panels of 1, 2, 4 rounds at config 4; 10 at config 5)
     assert s02.enc2_passenger and s02.node_stat_folded and s02.layer0_panels == 1
     assert not cfg4.enc2_passenger and not cfg4.node_stat_folded and cfg4.layer0_panels == 3
-    assert eng.plan(1_000_000, 100_000_000).layer0_panels == 10 and not trk.node_stat_folded and trk.enc2_passenger is False
+    assert eng.plan(1_000_000, 100_000_000).layer0_panels == 10 and not big.node_stat_folded and big.enc2_passenger is False
+    assert trk.node_stat_folded and trk.enc2_passenger
     assert eng.plan(1_000_000, 20_000_000).pass_a_col_blocks == 0          # 20 edges per row: sub-runs too short for 8 blocks
     assert eng.plan(1_000_000, 100_000_000, training=True).pass_a_col_blocks == 0
     det = eng.plan(100_000, 10_000_000, flags=_lib.F_DETERMINISTIC)
