@@ -8,9 +8,9 @@ import torch
 
 dev = torch.device("cuda:0")
 for m in [int(a) for a in sys.argv[1:]] or [100_000]:
-    for k in (2048, 6144):
+    for n, k in ((1024, 2048), (1024, 6144), (512, 3072)):      # layer 0 (K, 3K); layer 1 (3K)
         a = torch.randn(m, k, device=dev, dtype=torch.float16)
-        w = torch.randn(1024, k, device=dev, dtype=torch.float16)
+        w = torch.randn(n, k, device=dev, dtype=torch.float16)
         wt = w.t()
         for _ in range(5):
             torch.mm(a, wt)
@@ -24,6 +24,6 @@ for m in [int(a) for a in sys.argv[1:]] or [100_000]:
             e1.record()
             torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) / 20)
-        tf = 2.0 * m * 1024 * k / (best * 1e-3) / 1e12
-        print(f"M={m} N=1024 K={k}: {best:.3f} ms = {tf:.0f} TFLOP/s fp16 ({tf / 2500:.2f} of 2.5 PF)", flush=True)
+        tf = 2.0 * m * n * k / (best * 1e-3) / 1e12
+        print(f"M={m} N={n} K={k}: {best:.3f} ms = {tf:.0f} TFLOP/s fp16 ({tf / 2500:.2f} of 2.5 PF)", flush=True)
         del a, w, wt
