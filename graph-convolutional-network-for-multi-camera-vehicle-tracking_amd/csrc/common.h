@@ -254,8 +254,14 @@ static __device__ unsigned long long g_ek[kEkKernels * 2 * kEkPoints];
 // seed_tick_kernel at the start of the forward from the caller's device counter), so that a HIP graph that holds the whole
 // training step draws new masks on every replay; the backward of the same tape reads the same word.
 struct Drop { unsigned long long seed; unsigned thresh; float inv_keep; int on; };
-__device__ __forceinline__ unsigned long long drop_seed(const Drop& d) {
-  return d.on == 2 ? *reinterpret_cast<const unsigned long long*>(d.seed) : d.seed;      // (uniform: a scalar load)
+// Every kernel that draws masks calls drop_resolve on its own copy of the parameter ONCE, at its top (read inside drop_keep /
+// drop_apply -- per element -- the indirection cost the hashing kernels 25 us of a 600 us training step,
+// profiles/r05_seed_ab.txt); after it on is 0 or 1 and seed a value.
+__device__ __forceinline__ void drop_resolve(Drop& d) {
+  if (d.on == 2) {
+    d.seed = *reinterpret_cast<const unsigned long long*>(d.seed);      // (uniform: a scalar load)
+    d.on = 1;
+  }
 }
 
 __host__ __device__ __forceinline__ unsigned drop_hash(unsigned long long seed, unsigned stream, unsigned long long idx) {
@@ -266,11 +272,11 @@ __host__ __device__ __forceinline__ unsigned drop_hash(unsigned long long seed, 
   return (unsigned)(z >> 32);
 }
 __device__ __forceinline__ bool drop_keep(const Drop& d, unsigned stream, unsigned long long idx) {
-  return !d.on || drop_hash(drop_seed(d), stream, idx) >= d.thresh;
+  return !d.on || drop_hash(d.seed, stream, idx) >= d.thresh;
 }
 __device__ __forceinline__ float drop_apply(const Drop& d, unsigned stream, unsigned long long idx, float v) {
   if (!d.on) return v;
-  return drop_hash(drop_seed(d), stream, idx) >= d.thresh ? v * d.inv_keep : 0.f;
+  return drop_hash(d.seed, stream, idx) >= d.thresh ? v * d.inv_keep : 0.f;
 }
 // stream ids
 constexpr unsigned kDropEncEdge1 = 1, kDropEncEdge2 = 2, kDropEncNode = 100, kDropRound = 1000;   // +layer / +2r(+1)
@@ -363,8 +369,10 @@ __device__ __forceinline__ void load_attr(const float* attr, int fe, int64_t e, 
 
 // Moments of the edge encoder's hidden activations (enc2): workgroup `block` of `n_blocks`, 256 threads.  The body of
 // enc2_kernel (edge_kernels.hip) and of the passenger workgroups the few-row encoder GEMM carries (gemm_bn.hip).
-__device__ __forceinline__ void enc2_body(const EdgeEncParams& enc, const float* attr, int64_t n_edges, double e_total,
+__device__ __forceinline__ void enc2_body(const EdgeEncParams& enc_in, const float* attr, int64_t n_edges, double e_total,
                                           double* stat_enc2, int block, int n_blocks) {
+  EdgeEncParams enc = enc_in;
+  drop_resolve(enc.drop);
   __shared__ EdgeEncAffine af;
   __shared__ double red[14 * 4];
   edge_enc_affine_to_smem(enc, e_total, 1, &af, red);

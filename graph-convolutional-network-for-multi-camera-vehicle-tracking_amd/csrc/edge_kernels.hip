@@ -261,6 +261,7 @@ __device__ __forceinline__ void edge_z1(const RoundParams& p, const EdgeConstsS&
 
 template <int kEPT, int MODE, bool DROP>
 __global__ __launch_bounds__(256, (MODE == 0 ? 5 : 1)) void pass_a_kernel(RoundParams p) {   // plain later round: <= 96 VGPRs
+  if (DROP) drop_resolve(p.enc.drop);
   __shared__ EdgeConstsV cs_s;
   __shared__ double red[8 * 4];
   __shared__ PrevAffine pa_s;
@@ -521,6 +522,7 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 4 : 1)) void pass_a_blocked_kerne
 // products, runs of hundreds.
 template <int kEPT>
 __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
+  drop_resolve(p.drop_e);
   __shared__ float s1[4], t1[4];
   __shared__ double red[14 * 4 + 4 * 128 + 4];
   const int lane = threadIdx.x & 63;
@@ -795,6 +797,7 @@ __global__ __launch_bounds__(256) void agg_fixup_kernel(RoundParams p) {
 typedef float f32x16c __attribute__((ext_vector_type(16)));
 constexpr int kTileC = 256;   // tile = block size (128 and 512 measured slower at every graph size)
 __global__ __launch_bounds__(kTileC) void pass_c_kernel(RoundParams p) {
+  drop_resolve(p.drop_n);
   __shared__ float4 tile_e[kTileC];
   __shared__ int tile_row[kTileC];
   __shared__ double st[10 + 64];           // e' second moments (10) | z2 sums (32) | z2 sums of squares (32)
@@ -1500,6 +1503,7 @@ __global__ __launch_bounds__(256) void pass_c_sorted_kernel(RoundParams p, int s
 __global__ __launch_bounds__(256) void classify_e0_kernel(EdgeEncParams enc, const float* attr, int64_t n_edges,
                                                           double e_total, const float* cls_w, const float* cls_b,
                                                           int n_classes, float* logits) {
+  drop_resolve(enc.drop);
   __shared__ EdgeEncAffine af;
   __shared__ double scratch[kStatAttr + kStatEnc2];
   edge_enc_affine_to_smem(enc, e_total, 2, &af, scratch);

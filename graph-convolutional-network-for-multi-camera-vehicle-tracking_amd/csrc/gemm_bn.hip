@@ -30,6 +30,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // k-loop is a chain of dependent HBM/L2 round trips and a deeper tile halves their number.
 template <int TM, int TN, int BK>
 __global__ __launch_bounds__(256) void gemm_bn_kernel(GemmParams p, int tiles_m, int tiles_n) {
+  drop_resolve(p.drop_in);
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int LDK = BK + 4;                        // row stride 144 B / 272 B: conflict-free ds_read_b128
   constexpr int C4 = BK / 4;                         // float4 per tile row
@@ -218,6 +219,7 @@ __device__ __forceinline__ void split3(float x, __bf16& b1, __bf16& b2, __bf16& 
 
 template <int TM, int TN, int BK>
 __global__ __launch_bounds__(256) void gemm_bn_bf16x6_kernel(GemmParams p, int tiles_m, int tiles_n) {
+  drop_resolve(p.drop_in);
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int LDB = BK + 8;                         // 80 / 144-byte rows: conflict-free 16-byte fragment reads
   constexpr int C4 = BK / 4, A4 = BM * C4 / 256, B4 = BN * C4 / 256;
@@ -405,6 +407,7 @@ constexpr int kAffChunk = 512;   // input-affine columns resident in LDS (keeps 
 
 template <int TM, int TN, int BK>
 __global__ __launch_bounds__(256) void gemm_bn_f16x3_kernel(GemmParams p, int tiles_m, int tiles_n) {
+  drop_resolve(p.drop_in);
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int LDB = BK + 8;                         // 80 / 144-byte rows: conflict-free 16-byte fragment reads
   constexpr int C4 = BK / 4, A4 = BM * C4 / 256, B4 = BN * C4 / 256;

@@ -260,6 +260,7 @@ __global__ __launch_bounds__(512) void few_wave_kernel(FewWaveParams p) {
     enc2_body(p.pass_enc, p.pass_attr, p.pass_edges, p.pass_e_total, p.pass_stat, (int)blockIdx.x - p.tiles, p.pass_blocks);
     return;
   }
+  if (DROP) drop_resolve(p.drop_in);
   constexpr int KW = 32 * NKB;                            // K columns of one wave
   const int nw = (int)blockDim.x >> 6;
   float* aff = reinterpret_cast<float*>(smem);            // [nw][2][KW]

@@ -21,6 +21,7 @@ constexpr int kProjNodes = 16;   // nodes per block iteration (16 lanes per node
 constexpr int kProjOut = 40;     // 4 (Pr) + 4 (Pc) + 32 (Q)
 
 __global__ __launch_bounds__(256) void node_proj_kernel(NodeProjParams p) {
+  drop_resolve(p.drop);
   __shared__ float wt[64 * kProjOut];              // [k][j], k < hn
   __shared__ float hs[kProjNodes * 66];            // [node][k], row stride hn+2 (see the k loop)
   __shared__ float ys[kH], yt[kH];                 // BatchNorm affine of the encoder's last layer (fused round 0)
@@ -144,6 +145,7 @@ typedef float f32x4p __attribute__((ext_vector_type(4)));
 
 template <int HALVES>   // 1: hn = 32 (h only); 2: hn = 64 ([h0 | h], reattach_initial_nodes)
 __global__ __launch_bounds__(256) void node_proj_mfma_kernel(NodeProjParams p) {
+  drop_resolve(p.drop);
   __shared__ float ys[kH], yt[kH];
   __shared__ EdgeEncAffine enc_af;
   __shared__ double scratch[kStatAttr + kStatEnc2];
@@ -326,6 +328,7 @@ __global__ __launch_bounds__(256) void bn_relu_rows_kernel(const float* Y, int64
                                                            const double* stats, const float* gamma, const float* beta,
                                                            double count, float* dst, Drop drop, unsigned drop_stream,
                                                            int64_t row0, unsigned* amax_out, float* dstT, int64_t ldt) {
+  drop_resolve(drop);
   const int64_t total = rows * dim;
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
   float vmax = 0.f;
@@ -361,6 +364,7 @@ __global__ __launch_bounds__(256) void bn_relu_rows_t_kernel(const float* Y, int
                                                              const double* stats, const float* gamma, const float* beta,
                                                              double count, float* dst, Drop drop, unsigned drop_stream,
                                                              int64_t row0, unsigned* amax_out, float* dstT, int64_t ldt) {
+  drop_resolve(drop);
   __shared__ float tile[16][65];
   __shared__ float wmax[4];
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;

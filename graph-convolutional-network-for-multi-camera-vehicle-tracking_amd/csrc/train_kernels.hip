@@ -46,6 +46,7 @@ __device__ __forceinline__ void edge_weights_to_lds(const EdgeEncParams& enc, co
 }
 __device__ __forceinline__ EdgeEncParams enc_from_lds(const EdgeEncParams& enc, const EdgeWeightsLds* w) {
   EdgeEncParams e = enc;
+  drop_resolve(e.drop);
   e.w1 = w->w1; e.b1 = w->b1; e.w2 = w->w2; e.b2 = w->b2; e.g1 = w->g1; e.g2 = w->g2;
   return e;
 }
@@ -68,6 +69,7 @@ __device__ __forceinline__ void mean_istd(double sum, double sumsq, double count
 // ------------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(256) void bwd_node_upd_kernel(BwdRoundParams p) {
+  drop_resolve(p.f.drop_n);
   __shared__ float4 tile_e[256];
   __shared__ int tile_row[256];
   __shared__ double st[10 + 64 + 64];     // e' second moments | z2 sum, sumsq | (mode 1) sum g, sum g*zh
@@ -340,12 +342,7 @@ __global__ __launch_bounds__(256) void bwd_edge_upd_kernel(BwdRoundParams p) {
     }
   }
   // block reduction of NV doubles
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const double s = wave_sum(acc[i]);
-    if (lane == kWaveSumLane) red[wid * 64 + i] = s;
-  }
+  wave_sums_f64<NV>(acc, red + (threadIdx.x >> 6) * 64);      // (5 instructions per value instead of 18: common.h)
   __syncthreads();
   if (threadIdx.x < NV) {
     const int i = threadIdx.x;
@@ -459,6 +456,7 @@ __device__ __forceinline__ void moments_mean_istd(const float* w, int in_dim, fl
 
 template <int PASS>   // 0: stats of layer 2; 1: apply layer 2 + stats of layer 1; 2: apply layer 1
 __global__ __launch_bounds__(256) void bwd_edge_enc_kernel(BwdEncParams p) {
+  drop_resolve(p.enc.drop);
   __shared__ EdgeEncAffine af;
   __shared__ EncBwdShared sh;
   __shared__ double sc[kStatAttr + kStatEnc2 + 16];
@@ -555,12 +553,7 @@ __global__ __launch_bounds__(256) void bwd_edge_enc_kernel(BwdEncParams p) {
     }
     (void)za; (void)zb;
   }
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const double s = wave_sum(acc[i]);
-    if (lane == kWaveSumLane) red[wid * 64 + i] = s;
-  }
+  wave_sums_f64<NV>(acc, red + (threadIdx.x >> 6) * 64);      // (5 instructions per value instead of 18: common.h)
   __syncthreads();
   if (threadIdx.x < NV) {
     const int i = threadIdx.x;
@@ -591,6 +584,7 @@ constexpr int kBnBwdRows = 16;   // rows per workgroup: a few hundred node rows 
                                  // per workgroup: 12.4 / 8.1 us per launch at 430 x 1024)
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p) {
+  drop_resolve(p.drop);
   __shared__ double red[2 * 4 * 64];
   __shared__ float tile[MODE == 1 ? kBnBwdRows : 1][65];          // MODE 1: dY^T leaves as 16-byte stores, one per thread
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
@@ -755,6 +749,7 @@ __global__ __launch_bounds__(256) void bwd_classify_e0_kernel(EdgeEncParams enc,
                                                               double e_total, const float* cls_w, int n_classes,
                                                               const float* d_logits, float* g_e0, float* gr_cls_w,
                                                               float* gr_cls_b) {
+  drop_resolve(enc.drop);
   __shared__ EdgeEncAffine af;
   __shared__ double scratch[kStatAttr + kStatEnc2];
   __shared__ double red[64 * 4];
@@ -783,12 +778,7 @@ __global__ __launch_bounds__(256) void bwd_classify_e0_kernel(EdgeEncParams enc,
     }
     reinterpret_cast<float4*>(g_e0)[e] = make_float4(de[0], de[1], de[2], de[3]);
   }
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const double s = wave_sum(acc[i]);
-    if (lane == kWaveSumLane) red[wid * 64 + i] = s;
-  }
+  wave_sums_f64<NV>(acc, red + (threadIdx.x >> 6) * 64);      // (5 instructions per value instead of 18: common.h)
   __syncthreads();
   if (threadIdx.x < NV) {
     const int i = threadIdx.x;
