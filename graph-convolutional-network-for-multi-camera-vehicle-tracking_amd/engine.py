@@ -112,8 +112,9 @@ class ForwardEngine:
 
     def model_struct(self, dev, params=None) -> _lib.Model:
         params = self.params() if params is None else params
-        # the struct only changes when a parameter's storage does: key it on the device pointers
-        key = (dev,) + tuple(t.data_ptr() for t in params)
+        # the struct only changes when a parameter's storage does: key it on the device pointers -- and on what _check_param
+        # looks at, since an allocator can hand a recycled address to a tensor of another dtype or shape (e.g. after .half())
+        key = (dev,) + tuple((t.data_ptr(), t.dtype, t.shape, t.stride()) for t in params)
         if key == self._ms_key:
             return _lib.Model.from_buffer_copy(self._ms)
         s = self.spec

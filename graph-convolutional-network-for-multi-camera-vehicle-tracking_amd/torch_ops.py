@@ -67,6 +67,13 @@ def grad_layout(spec):
     return res
 
 
+def _grad_views(flat, layout):
+    """The 34 gradient tensors as views of the flat buffer: one as_strided each (a slice + a view per tensor was 68 dispatcher
+    calls per backward, a tenth of the launch-by-launch step's host time on a slow host)."""
+    base = flat.storage_offset()
+    return [flat.as_strided(shp, (shp[1], 1) if len(shp) == 2 else (1,), base + o) for o, _, shp in layout]
+
+
 def _layer_slots(spec):
     from .engine import layer_slots
     return layer_slots(spec)
@@ -215,7 +222,7 @@ def _autograd_backward(ctx, d_logits, d_h, _d_tape):
                                                       ctx.seed, ctx.flags, d_logits, d_h, ctx.need_x, ctx.need_attr)
     spec = engine_for(ctx.config).spec
     layout, _ = grad_layout(spec)
-    grads = [flat[o:o + n].view(shp) for o, n, shp in layout]
+    grads = _grad_views(flat, layout)
     if spec.num_enc_steps == 0:               # the update MLPs took no part: None, as autograd gives the reference
         from .engine import layer_slots
         i = 0
@@ -271,7 +278,7 @@ class _MpForwardLean(torch.autograd.Function):
                                        None, d_h, ctx.need_x, ctx.need_attr, prep=prep, d_steps=d_steps)
         spec = engine_for(ctx.config).spec
         layout, _ = grad_layout(spec)
-        grads = [flat[o:o + n].view(shp) for o, n, shp in layout]
+        grads = _grad_views(flat, layout)
         if spec.num_enc_steps == 0:           # the update MLPs took no part: None, as autograd gives the reference
             i = 0
             for slot, _, layer in _layer_slots(spec):
