@@ -206,16 +206,24 @@ static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
       unsigned* amax_act = x.at<unsigned>(lo.amax_bwd) + (size_t)(MTMC_MAX_ENC_LAYERS + l) * mtmc::kAmaxRep;
       bb.amax_out = amax_dy;
       bb.dT = tA; bb.ldt = npad;                                       // dY_l^T comes out of the apply pass directly
-      mtmc::launch_bn_bwd(bb, 0, s);
-      mtmc::launch_bn_bwd(bb, 1, s);                                   // dY now holds dY_l
-      // the layer's input activation a_{l-1}: x itself, or relu(bn(Y_{l-1})) with its dropout mask
+      // the layer's input activation a_{l-1}: x itself, or relu(bn(Y_{l-1})) with its dropout mask -- recomputed (with its
+      // transpose and its |.|max) by the z = 1 workgroups of the apply launch: nothing of it depends on dY_l
       const float* aT = tX;                                            // a_{l-1}^T [in][npad]
+      const bool ride = l > 0 && mtmc::bn_bwd_carries_rows_job(N, npad);
       if (l > 0) {
+        const mtmc_layer& Pv = m->enc_node[l - 1];
+        bb.rc = {x.at<float>(lo.Y[l - 1]), Pv.out_dim, N, Pv.out_dim, x.at<double>(lo.stat_enc_layer[l - 1]), Pv.gamma, Pv.beta,
+                 (double)N, gB, make_drop(x, m->dropout_enc), mtmc::kDropEncNode + l - 1, 0, amax_act, tB, npad};
+        bb.rc_on = ride ? 1 : 0;
+        aT = tB;
+      }
+      mtmc::launch_bn_bwd(bb, 0, s);
+      mtmc::launch_bn_bwd(bb, 1, s);                                   // dY now holds dY_l (+ a_{l-1}, a_{l-1}^T)
+      if (l > 0 && !ride) {
         const mtmc_layer& Pv = m->enc_node[l - 1];
         mtmc::launch_bn_relu_rows(x.at<float>(lo.Y[l - 1]), Pv.out_dim, N, Pv.out_dim, x.at<double>(lo.stat_enc_layer[l - 1]),
                                   Pv.gamma, Pv.beta, (double)N, gB, make_drop(x, m->dropout_enc), mtmc::kDropEncNode + l - 1, 0, s,
-                                  amax_act, tB, npad);               // ... and a_{l-1}^T out of its recomputation
-        aT = tB;
+                                  amax_act, tB, npad);
       }
       // dW_l [d][in] = dY^T . a  -> NT GEMM on the transposes (reduction over the node rows, padded to 32)
       mtmc::GemmParams g;

@@ -10,6 +10,7 @@
 //   bn_relu_rows      h0 = relu(bn(Y_last))
 //   h_final           latent_node_feats output (mean aggregation divides by max(deg,1))
 #include "kernels.h"
+#include "rows_body.h"
 
 namespace mtmc {
 
@@ -360,47 +361,9 @@ __global__ __launch_bounds__(256) void bn_relu_rows_kernel(const float* Y, int64
 // the weight-gradient GEMM's operand): 16 rows x 64 columns per workgroup, a thread keeps ONE column -- its BatchNorm affine is
 // derived once, not per element -- and the transposed tile leaves through LDS as one 16-byte store per thread (round 5: the
 // element-per-thread loop above took 6 / 10 / 15 us for 430 x 128 / 512 / 1024, most of it fp64 affines and 4-byte scattered stores).
-__global__ __launch_bounds__(256) void bn_relu_rows_t_kernel(const float* Y, int64_t ldy, int64_t rows, int dim,
-                                                             const double* stats, const float* gamma, const float* beta,
-                                                             double count, float* dst, Drop drop, unsigned drop_stream,
-                                                             int64_t row0, unsigned* amax_out, float* dstT, int64_t ldt) {
-  drop_resolve(drop);
-  __shared__ float tile[16][65];
-  __shared__ float wmax[4];
-  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + cl;
-  const int64_t r0 = (int64_t)blockIdx.y * 16;
-  float vmax = 0.f;
-  float s = 0.f, t = 0.f;
-  if (col < dim) bn_affine(stats[col], stats[dim + col], count, gamma[col], beta[col], s, t);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int64_t r = r0 + rg + 4 * i;
-    float v = 0.f;
-    if (r < rows && col < dim) {
-      v = drop_apply(drop, drop_stream, (unsigned long long)(row0 + r) * dim + col, fmaxf(fmaf(Y[r * ldy + col], s, t), 0.f));
-      dst[r * dim + col] = v;
-    }
-    tile[rg + 4 * i][cl] = v;                       // (rows past the end: the transposed copy's zero padding)
-    vmax = fmaxf(vmax, v);
-  }
-  __syncthreads();
-  {
-    const int c = threadIdx.x >> 2, q = threadIdx.x & 3;      // column of the tile, quarter of its 16 rows
-    if (blockIdx.x * 64 + c < dim && r0 + 4 * q < ldt)        // (ldt % 4 == 0: a quarter is inside or outside as a whole)
-      *reinterpret_cast<float4*>(dstT + (int64_t)(blockIdx.x * 64 + c) * ldt + r0 + 4 * q) =
-          make_float4(tile[4 * q][c], tile[4 * q + 1][c], tile[4 * q + 2][c], tile[4 * q + 3][c]);
-  }
-  if (blockIdx.y == gridDim.y - 1 && col < dim)             // padding rows behind the last tile
-    for (int64_t r = r0 + 16 + rg; r < ldt; r += 4) dstT[(int64_t)col * ldt + r] = 0.f;
-  if (amax_out) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
-    if (cl == 0) wmax[rg] = vmax;
-    __syncthreads();
-    if (threadIdx.x == 0)
-      amax_publish(amax_out + (blockIdx.x + blockIdx.y) % kAmaxRep, fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
-  }
+__global__ __launch_bounds__(256) void bn_relu_rows_t_kernel(RowsTJob j) {
+  drop_resolve(j.drop);
+  bn_relu_rows_t_body(j, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
 __global__ __launch_bounds__(256) void h_final_kernel(const float* src, const int* deg, int mean, int64_t n_nodes,
@@ -433,8 +396,8 @@ void launch_bn_relu_rows(const float* Y, int64_t ldy, int64_t rows, int dim, con
                          const float* beta, double count, float* dst, Drop drop, unsigned drop_stream, int64_t row0,
                          hipStream_t s, unsigned* amax_out, float* dstT, int64_t ldt) {
   if (dstT && ldt % 4 == 0 && rows > 0 && (rows + 15) / 16 <= 65535) {
-    hipLaunchKernelGGL(bn_relu_rows_t_kernel, dim3((dim + 63) / 64, (unsigned)((rows + 15) / 16)), dim3(256), 0, s, Y, ldy, rows,
-                       dim, stats, gamma, beta, count, dst, drop, drop_stream, row0, amax_out, dstT, ldt);
+    const RowsTJob j = {Y, ldy, rows, dim, stats, gamma, beta, count, dst, drop, drop_stream, row0, amax_out, dstT, ldt};
+    hipLaunchKernelGGL(bn_relu_rows_t_kernel, dim3((dim + 63) / 64, (unsigned)((rows + 15) / 16)), dim3(256), 0, s, j);
     return;
   }
   // with the |.|max bookkeeping: one workgroup per CU, so that at most 16 of them meet on a word

@@ -1,6 +1,7 @@
 // Launch interface of the backward kernels (train_kernels.hip).
 #pragma once
 #include "kernels.h"
+#include "rows_body.h"
 
 namespace mtmc {
 
@@ -69,6 +70,8 @@ struct BnBwdParams {
   float* gr_gamma; float* gr_beta; float* gr_bias;
   unsigned* amax_out;        // u32[kAmaxRep] |dY|max (mode 1; atomicMax on the bit patterns), or nullptr
   float* dT; int64_t ldt;    // mode 1: dY^T [dim][ldt] as well (rows..ldt zero-filled): the weight-gradient GEMM's operand
+  RowsTJob rc; int rc_on = 0;  // mode 1: the recomputation of the layer's INPUT activation (+ its transpose) rides as the z = 1
+                               // workgroups of the launch (independent of this layer's dY); same rows, 16 per workgroup
 };
 
 void launch_bwd_node_upd(const BwdRoundParams& p, int mode, hipStream_t s);
@@ -80,6 +83,7 @@ void launch_bwd_classify_e0(const EdgeEncParams& enc, const float* attr, int64_t
                             int n_classes, const float* d_logits, float* g_e0, float* gr_cls_w, float* gr_cls_b,
                             hipStream_t s);
 void launch_bn_bwd(const BnBwdParams& p, int mode, hipStream_t s);
+bool bn_bwd_carries_rows_job(int64_t rows, int64_t ldt);      // the shapes bn_relu_rows_t_body takes
 void launch_transpose_pad(const float* src, int64_t rows, int cols, int64_t ld_src, float* dst, int64_t rows_pad,
                           hipStream_t s);
 // what the backward accumulates into, cleared by ONE launch: the gaps between the node encoder's weight gradients in the caller's

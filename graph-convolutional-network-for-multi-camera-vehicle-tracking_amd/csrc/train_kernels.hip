@@ -584,6 +584,13 @@ constexpr int kBnBwdRows = 16;   // rows per workgroup: a few hundred node rows 
                                  // per workgroup: 12.4 / 8.1 us per launch at 430 x 1024)
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p) {
+  if (MODE == 1 && blockIdx.z == 1) {               // passenger: relu(bn(Y_{l-1})) and its transpose (rows_body.h)
+    RowsTJob j = p.rc;
+    drop_resolve(j.drop);
+    if ((int)blockIdx.x * 64 < j.dim) bn_relu_rows_t_body(j, blockIdx.x, blockIdx.y, gridDim.y);
+    return;
+  }
+  if ((int)blockIdx.x * 64 >= p.dim) return;        // (the grid is as wide as the wider of the two jobs)
   drop_resolve(p.drop);
   __shared__ double red[2 * 4 * 64];
   __shared__ float tile[MODE == 1 ? kBnBwdRows : 1][65];          // MODE 1: dY^T leaves as 16-byte stores, one per thread
@@ -801,10 +808,17 @@ void launch_bwd_edge_enc(const BwdEncParams& p, int pass, hipStream_t s) {
   else hipLaunchKernelGGL(bwd_edge_enc_kernel<2>, dim3(grid), dim3(256), 0, s, p);
 }
 void launch_bn_bwd(const BnBwdParams& p, int mode, hipStream_t s) {
-  const dim3 grid((p.dim + 63) / 64, (unsigned)((p.rows + kBnBwdRows - 1) / kBnBwdRows));
-  if (mode == 0) hipLaunchKernelGGL(bn_bwd_kernel<0>, grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(bn_bwd_kernel<1>, grid, dim3(256), 0, s, p);
+  dim3 grid((p.dim + 63) / 64, (unsigned)((p.rows + kBnBwdRows - 1) / kBnBwdRows));
+  if (mode == 0) { hipLaunchKernelGGL(bn_bwd_kernel<0>, grid, dim3(256), 0, s, p); return; }
+  if (p.rc_on) {                                     // + the recomputation job: z = 1, the wider of the two in x
+    static_assert(kBnBwdRows == 16, "both jobs cut the rows in 16s");
+    const unsigned xb = (unsigned)(p.rc.dim + 63) / 64;
+    grid.x = grid.x > xb ? grid.x : xb;
+    grid.z = 2;
+  }
+  hipLaunchKernelGGL(bn_bwd_kernel<1>, grid, dim3(256), 0, s, p);
 }
+bool bn_bwd_carries_rows_job(int64_t rows, int64_t ldt) { return ldt % 4 == 0 && rows > 0 && (rows + 15) / 16 <= 65535; }
 void launch_transpose_pad(const float* src, int64_t rows, int cols, int64_t ld_src, float* dst, int64_t rows_pad,
                           hipStream_t s) {
   hipLaunchKernelGGL(transpose_pad_kernel, dim3((unsigned)((rows_pad + 31) / 32), (cols + 31) / 32), dim3(256), 0, s,
