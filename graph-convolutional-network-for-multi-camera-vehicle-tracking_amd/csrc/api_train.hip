@@ -51,6 +51,22 @@ static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
   // gradient buffers are accumulated into with atomics: clear them first (the caller only provides storage).
   // One memset when the caller carved all of them out of one buffer (grads_flat), else one per tensor; the node
   // encoder's weight gradients are plain GEMM outputs and need none.
+  // x^T and every W_l^T the node encoder's backward multiplies by depend on nothing the backward computes: they are made by the
+  // backward's FIRST launch, beside the clearing of what it accumulates into
+  float* tWl[MTMC_MAX_ENC_LAYERS] = {};
+  float* tX = x.at<float>(lo.tX);
+  const int64_t npad = (N + 31) / 32 * 32;
+  mtmc::TransposeJobs tj;
+  {
+    mtmc::transpose_jobs_add(tj, call->x, N, m->enc_node[0].in_dim, call->x_row_stride, tX, npad);
+    float* w = x.at<float>(lo.tW);
+    for (int l = 0; l < m->n_enc_layers; ++l) {
+      const mtmc_layer& Lr = m->enc_node[l];
+      if (l > 0 || d_x) { tWl[l] = w; mtmc::transpose_jobs_add(tj, Lr.weight, Lr.out_dim, Lr.in_dim, Lr.in_dim, w, Lr.out_dim); }
+      w += (size_t)Lr.in_dim * Lr.out_dim;
+    }
+  }
+  bool transposed = false;
   auto zero = [&](float* p, size_t n) { return hipMemsetAsync(p, 0, n * sizeof(float), s); };
   bool ws_zeroed = false;
   if (grads_flat) {
@@ -73,8 +89,8 @@ static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
     }
     if (ok) {
       z.r[z.n].p = reinterpret_cast<uint4*>(x.ws + lo.bwd_zero); z.r[z.n].n16 = (lo.bwd_zero_end - lo.bwd_zero) / 16; ++z.n;
-      mtmc::launch_zero_ranges(z, s);
-      ws_zeroed = true;
+      mtmc::launch_bwd_begin(z, tj, s);
+      ws_zeroed = transposed = true;
     } else {
       HIP_OK(hipMemsetAsync(grads_flat, 0, grads_flat_bytes, s));
     }
@@ -95,6 +111,7 @@ static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
   }
   // the workspace side: statistics blocks, per-round dP/dQ, dh0, de0, the first de / dh buffers -- one range
   if (!ws_zeroed) HIP_OK(hipMemsetAsync(x.ws + lo.bwd_zero, 0, lo.bwd_zero_end - lo.bwd_zero, s));
+  if (!transposed) mtmc::launch_transpose_multi(tj, s);
   int cur = 0, cur_e = 0;
   if (d_h) HIP_OK(hipMemcpyAsync(L > 0 ? g_h[cur] : g_h0, d_h, (size_t)N * 32 * sizeof(float), hipMemcpyDeviceToDevice, s));
   if (L == 0 && d_logits_steps && d_logits_steps[0] && E > 0)       // no rounds: classifier on the encoded edges
@@ -167,23 +184,7 @@ static int backward_impl(const mtmc_mpn_model* model, const mtmc_mpn_call* call,
     float* gB = x.at<float>(lo.gB);
     float* tA = x.at<float>(lo.tA);
     float* tB = x.at<float>(lo.tB);
-    float* tW = x.at<float>(lo.tW);
     float* zeros = x.at<float>(lo.zeros);
-    const int64_t npad = (N + 31) / 32 * 32;
-    // x^T and every W_l^T the loop below multiplies by: known before its first kernel, one launch for all of them
-    float* tWl[MTMC_MAX_ENC_LAYERS] = {};
-    float* tX = x.at<float>(lo.tX);
-    {
-      mtmc::TransposeJobs tj;
-      mtmc::transpose_jobs_add(tj, call->x, N, m->enc_node[0].in_dim, call->x_row_stride, tX, npad);
-      float* w = tW;
-      for (int l = 0; l < m->n_enc_layers; ++l) {
-        const mtmc_layer& Lr = m->enc_node[l];
-        if (l > 0 || d_x) { tWl[l] = w; mtmc::transpose_jobs_add(tj, Lr.weight, Lr.out_dim, Lr.in_dim, Lr.in_dim, w, Lr.out_dim); }
-        w += (size_t)Lr.in_dim * Lr.out_dim;
-      }
-      mtmc::launch_transpose_multi(tj, s);
-    }
     const mtmc::Drop nodrop = {0, 0, 1.f, 0};
     for (int l = m->n_enc_layers - 1; l >= 0; --l) {
       const mtmc_layer& Lr = m->enc_node[l];

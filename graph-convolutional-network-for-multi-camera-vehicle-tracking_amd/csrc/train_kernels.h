@@ -95,5 +95,6 @@ struct TransposeJob { const float* src; float* dst; int64_t rows, ld_src, rows_p
 struct TransposeJobs { int n = 0; unsigned n_blocks = 0; TransposeJob job[MTMC_MAX_ENC_LAYERS + 1]; };
 void transpose_jobs_add(TransposeJobs& p, const float* src, int64_t rows, int cols, int64_t ld_src, float* dst, int64_t rows_pad);
 void launch_transpose_multi(const TransposeJobs& p, hipStream_t s);
+void launch_bwd_begin(const ZeroRanges& z, const TransposeJobs& t, hipStream_t s);    // both in one launch (the backward's first)
 
 }  // namespace mtmc

@@ -685,12 +685,12 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* src, in
 
 // The same for several matrices in ONE launch (the node encoder's backward needs x^T and every W_l^T, all of them known before
 // its first kernel: four 5 us launches on the chain become one).  1-D grid; a block finds its matrix by the block prefix.
-__global__ __launch_bounds__(256) void transpose_multi_kernel(TransposeJobs p) {
+__device__ __forceinline__ void transpose_job_body(const TransposeJobs& p, unsigned block) {
   __shared__ float tile[32][33];
   int j = 0;
-  while (j + 1 < p.n && blockIdx.x >= p.job[j + 1].first_block) ++j;
+  while (j + 1 < p.n && block >= p.job[j + 1].first_block) ++j;
   const TransposeJob& q = p.job[j];
-  const unsigned b = blockIdx.x - q.first_block;
+  const unsigned b = block - q.first_block;
   const int64_t r0 = (int64_t)(b % q.blocks_r) * 32;
   const int c0 = (int)(b / q.blocks_r) * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -706,6 +706,7 @@ __global__ __launch_bounds__(256) void transpose_multi_kernel(TransposeJobs p) {
     if (c < q.cols && r < q.rows_pad) q.dst[(int64_t)c * q.rows_pad + r] = tile[tx][i];
   }
 }
+__global__ __launch_bounds__(256) void transpose_multi_kernel(TransposeJobs p) { transpose_job_body(p, blockIdx.x); }
 
 // ------------------------------------------------------------------------------------------------
 // launchers
@@ -829,6 +830,25 @@ __global__ __launch_bounds__(256) void zero_ranges_kernel(ZeroRanges z) {
   const size_t nthreads = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (int j = 0; j < z.n; ++j)
     for (size_t i = t0; i < z.r[j].n16; i += nthreads) z.r[j].p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+// The backward's first launch: what it accumulates into is cleared by the first n_zero workgroups, x^T and every W_l^T (which
+// depend on nothing the backward computes) are made by the rest.
+__global__ __launch_bounds__(256) void bwd_begin_kernel(ZeroRanges z, TransposeJobs t, unsigned n_zero) {
+  if (blockIdx.x < n_zero) {
+    const size_t nthreads = (size_t)n_zero * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int j = 0; j < z.n; ++j)
+      for (size_t i = t0; i < z.r[j].n16; i += nthreads) z.r[j].p[i] = make_uint4(0u, 0u, 0u, 0u);
+    return;
+  }
+  transpose_job_body(t, blockIdx.x - n_zero);
+}
+void launch_bwd_begin(const ZeroRanges& z, const TransposeJobs& t, hipStream_t s) {
+  size_t total = 0;
+  for (int j = 0; j < z.n; ++j) total += z.r[j].n16;
+  const size_t blocks = (total + 1023) / 1024;
+  const unsigned nz = (unsigned)(blocks > 2048 ? 2048 : blocks);
+  if (nz + t.n_blocks == 0) return;
+  hipLaunchKernelGGL(bwd_begin_kernel, dim3(nz + t.n_blocks), dim3(256), 0, s, z, t, nz);
 }
 void launch_zero_ranges(const ZeroRanges& z, hipStream_t s) {
   size_t total = 0;
