@@ -298,8 +298,8 @@ inline mtmc::Drop make_drop(const Ctx& x, float p) {
     d.on = 2;
     d.seed = (unsigned long long)(uintptr_t)(x.ws + x.lo.seed_word);
   }
-  const double t = (double)p * 4294967296.0;
-  d.thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+  const double t = (double)p * 65536.0;                 // 16-bit fields: four elements per 64-bit hash (common.h)
+  d.thresh = t >= 65535.0 ? 65535u : (unsigned)t;
   d.inv_keep = p < 1.f ? 1.f / (1.f - p) : 0.f;
   return d;
 }

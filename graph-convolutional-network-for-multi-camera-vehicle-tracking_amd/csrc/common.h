@@ -249,7 +249,12 @@ static __device__ unsigned long long g_ek[kEkKernels * 2 * kEkPoints];
 
 // Dropout (training mode only; reference models/mlp.py:21-22): counter-based, so any kernel -- forward or
 // backward, or the CPU model in tests/ -- regenerates the same mask from (seed, stream, element index).
-// keep iff hash >= thresh, thresh = p * 2^32; kept values are scaled by 1/(1-p).
+// ONE 64-bit hash serves FOUR consecutive elements (round 5: a hash per element was most of what Dropout cost -- 30-odd
+// instructions of 64-bit integer arithmetic for every activation): element idx belongs to group idx >> 2 and reads 16-bit field
+// idx & 3 of the group's hash; keep iff field >= thresh, thresh = p * 2^16; kept values are scaled by 1/(1-p).  Kernels whose
+// lanes hold four consecutive elements (drop_keep4 / drop_apply4) hash once per four; the element-wise calls agree with them.
+// The node update's messages [E][32] are indexed CHANNEL-major for this (drop_msg_index): their kernels keep one channel per
+// lane and walk along the edges, so four consecutive edges of a channel share a hash.
 // on == 2 (MTMC_F_SEED_ON_DEVICE): `seed` is the ADDRESS of the seed word of this forward in the workspace / tape (written by
 // seed_tick_kernel at the start of the forward from the caller's device counter), so that a HIP graph that holds the whole
 // training step draws new masks on every replay; the backward of the same tape reads the same word.
@@ -264,19 +269,44 @@ __device__ __forceinline__ void drop_resolve(Drop& d) {
   }
 }
 
-__host__ __device__ __forceinline__ unsigned drop_hash(unsigned long long seed, unsigned stream, unsigned long long idx) {
-  unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull + (unsigned long long)stream * 0xBF58476D1CE4E5B9ull;
+__host__ __device__ __forceinline__ unsigned long long drop_hash4(unsigned long long seed, unsigned stream, unsigned long long group) {
+  unsigned long long z = group + seed * 0x9E3779B97F4A7C15ull + (unsigned long long)stream * 0xBF58476D1CE4E5B9ull;
   z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
   z ^= z >> 27; z *= 0x94D049BB133111EBull;
   z ^= z >> 31;
-  return (unsigned)(z >> 32);
+  return z;
+}
+__device__ __forceinline__ bool drop_field(const Drop& d, unsigned long long z, int j) {     // j = element index & 3
+  return ((unsigned)(z >> (16 * j)) & 0xffffu) >= d.thresh;
 }
 __device__ __forceinline__ bool drop_keep(const Drop& d, unsigned stream, unsigned long long idx) {
-  return !d.on || drop_hash(d.seed, stream, idx) >= d.thresh;
+  return !d.on || drop_field(d, drop_hash4(d.seed, stream, idx >> 2), (int)(idx & 3));
 }
 __device__ __forceinline__ float drop_apply(const Drop& d, unsigned stream, unsigned long long idx, float v) {
   if (!d.on) return v;
-  return drop_hash(d.seed, stream, idx) >= d.thresh ? v * d.inv_keep : 0.f;
+  return drop_field(d, drop_hash4(d.seed, stream, idx >> 2), (int)(idx & 3)) ? v * d.inv_keep : 0.f;
+}
+// four consecutive elements idx .. idx + 3 (idx % 4 == 0: one hash; anything else: element by element)
+__device__ __forceinline__ void drop_apply4(const Drop& d, unsigned stream, unsigned long long idx, float (&v)[4]) {
+  if (!d.on) return;
+  if ((idx & 3) == 0) {
+    const unsigned long long z = drop_hash4(d.seed, stream, idx >> 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // (one v_mul_f32 each, kept apart: paired up by the SLP vectoriser they become v_pk_mul_f32 with op_sel on the scalar
+      //  pair that holds inv_keep -- the form tools/check_isa.py bans from kernels with MFMAs)
+      float r = v[j] * d.inv_keep;
+      asm volatile("" : "+v"(r));
+      v[j] = drop_field(d, z, j) ? r : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = drop_apply(d, stream, idx + j, v[j]);
+  }
+}
+// element index of message (edge e, channel k) of the node update: channel-major over the edge count padded to 4
+__host__ __device__ __forceinline__ unsigned long long drop_msg_index(long long e, int k, long long n_edges) {
+  return (unsigned long long)k * (unsigned long long)((n_edges + 3) & ~3ll) + (unsigned long long)e;
 }
 // stream ids
 constexpr unsigned kDropEncEdge1 = 1, kDropEncEdge2 = 2, kDropEncNode = 100, kDropRound = 1000;   // +layer / +2r(+1)
@@ -349,8 +379,9 @@ __device__ __forceinline__ void edge_enc_hidden(const EdgeEncParams& p, const Ed
   for (int k = 0; k < 4; ++k) {
     float z = p.b1[k] + p.w1[k * p.fe] * a0;
     if (p.fe > 1) z = fmaf(p.w1[k * p.fe + 1], a1, z);
-    u[k] = drop_apply(p.drop, kDropEncEdge1, (unsigned long long)e * 4 + k, fmaxf(fmaf(z, af.s1[k], af.t1[k]), 0.f));
+    u[k] = fmaxf(fmaf(z, af.s1[k], af.t1[k]), 0.f);
   }
+  drop_apply4(p.drop, kDropEncEdge1, (unsigned long long)e * 4, u);      // the edge's four channels: one hash
 }
 
 // e0 = relu(bn2(W2 u + b2)) : output of the edge encoder
@@ -361,8 +392,9 @@ __device__ __forceinline__ void edge_enc_out(const EdgeEncParams& p, const EdgeE
     float z = p.b2[k];
 #pragma unroll
     for (int j = 0; j < 4; ++j) z = fmaf(p.w2[k * 4 + j], u[j], z);
-    e[k] = drop_apply(p.drop, kDropEncEdge2, (unsigned long long)eidx * 4 + k, fmaxf(fmaf(z, af.s2[k], af.t2[k]), 0.f));
+    e[k] = fmaxf(fmaf(z, af.s2[k], af.t2[k]), 0.f);
   }
+  drop_apply4(p.drop, kDropEncEdge2, (unsigned long long)eidx * 4, e);
 }
 
 __device__ __forceinline__ void load_attr(const float* attr, int fe, int64_t e, float& a0, float& a1);

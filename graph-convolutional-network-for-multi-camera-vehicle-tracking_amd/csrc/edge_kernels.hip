@@ -215,16 +215,16 @@ __device__ __forceinline__ void edge_z1(const RoundParams& p, const EdgeConstsS&
     for (int k = 0; k < 4; ++k) {                       // edge_enc_hidden, scalar operands (edge_in_dim 1: w1[k][1] = a1 = 0)
       const float zz = fmaf(ks.w1[k][1], in.a1, ks.b1[k] + ks.w1[k][0] * in.a0);
       u[k] = fmaxf(fmaf(zz, ks.s1[k], ks.t1[k]), 0.f);
-      if (DROP) u[k] = drop_apply(p.enc.drop, kDropEncEdge1, (unsigned long long)e * 4 + k, u[k]);
     }
+    if (DROP) drop_apply4(p.enc.drop, kDropEncEdge1, (unsigned long long)e * 4, u);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {                       // edge_enc_out
       float zz = c.b2[k];
 #pragma unroll
       for (int j = 0; j < 4; ++j) zz = fmaf(c.w2[k][j], u[j], zz);
       e0[k] = fmaxf(fmaf(zz, c.s2[k], c.t2[k]), 0.f);
-      if (DROP) e0[k] = drop_apply(p.enc.drop, kDropEncEdge2, (unsigned long long)e * 4 + k, e0[k]);
     }
+    if (DROP) drop_apply4(p.enc.drop, kDropEncEdge2, (unsigned long long)e * 4, e0);
   }
   if (first_round) {
 #pragma unroll
@@ -611,8 +611,8 @@ __global__ __launch_bounds__(256) void pass_b_kernel(RoundParams p) {
       if (full || e < p.n_edges) {
         const float z4[4] = {zz[i].x, zz[i].y, zz[i].z, zz[i].w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          vv[i][k] = drop_apply(p.drop_e, p.drop_stream, (unsigned long long)e * 4 + k, fmaxf(fmaf(z4[k], s1[k], t1[k]), 0.f));
+        for (int k = 0; k < 4; ++k) vv[i][k] = fmaxf(fmaf(z4[k], s1[k], t1[k]), 0.f);
+        drop_apply4(p.drop_e, p.drop_stream, (unsigned long long)e * 4, vv[i]);
         if (!p.lazy_e) reinterpret_cast<float4*>(p.e_out)[e] = make_float4(vv[i][0], vv[i][1], vv[i][2], vv[i][3]);
       }
     }
@@ -881,9 +881,12 @@ __global__ __launch_bounds__(kTileC) void pass_c_kernel(RoundParams p) {
     int cur = -1;
     bool first = true;
     float acc = 0.f, c0 = 0.f;
+    unsigned long long zd = 0;               // Dropout: the hash of four consecutive edges of this lane's channel (common.h)
     for (int j = 0; j < n_here; ++j) {
       const int r = tile_row[hw * 32 + j];
       const float4 v = tile_e[hw * 32 + j];
+      if (p.drop_n.on && (j & 3) == 0)
+        zd = drop_hash4(p.drop_n.seed, p.drop_stream + 1, drop_msg_index(base + hw * 32 + j, k, p.n_edges) >> 2);
       if (r != cur) {
         if (cur >= 0) { flush_run(p, det, chunk, first ? 0 : -1, cur, k, acc); first = false; }
         cur = r;
@@ -891,7 +894,7 @@ __global__ __launch_bounds__(kTileC) void pass_c_kernel(RoundParams p) {
         c0 = fmaf(sk, p.Q[(int64_t)r * kH + k], cb);
       }
       float m = fmaxf(fmaf(a4[3], v.w, fmaf(a4[2], v.z, fmaf(a4[1], v.y, fmaf(a4[0], v.x, c0)))), 0.f);
-      m = drop_apply(p.drop_n, p.drop_stream + 1, (unsigned long long)(base + hw * 32 + j) * kH + k, m);
+      if (p.drop_n.on) m = drop_field(p.drop_n, zd, j & 3) ? m * p.drop_n.inv_keep : 0.f;
       acc = (p.agg == 2) ? fmaxf(acc, m) : acc + m;
     }
     if (cur >= 0) flush_run(p, det, chunk, first ? 0 : 1, cur, k, acc);
@@ -917,7 +920,9 @@ __global__ __launch_bounds__(kTileC) void pass_c_kernel(RoundParams p) {
 // ------------------------------------------------------------------------------------------------
 // 64-edge chunks per wave span (runs are carried inside a span; one span per wave, so the grid balances itself)
 
+template <bool DROP>        // DROP (training, few-edge lists): the node update's Dropout on the messages, per accumulator register
 __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int span_c) {
+  if (DROP) drop_resolve(p.drop_n);
   __shared__ double st[10 + 64];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: spans, chunks, rows stay scalar
@@ -1005,12 +1010,16 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
     };
     // sum of relu over the lane's 16 values.  relu as a signed-integer max: exact for every float (negative values and
     // -0 have the sign bit set), and free of the canonicalising v_max_f32 x, x, x that fmaxf puts in front
-    auto relu_sum = [&](const f32x16c& acc) -> float {
+    // DROP: keep[g][i] = 1/(1-p) or 0 for register i of group g (edge 64 chunk + 32 g + (i&3) + 8 (i>>2) + 4 hi, channel k:
+    // drop_msg_index, what the walk and the backward hash too), taken once per chunk: eight hashes for the 32 registers
+    float keep[2][16];
+    auto relu_sum = [&](const f32x16c& acc, int g) -> float {
       float s0 = 0.f, s1 = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; i += 2) {
-        s0 += __int_as_float(max(__float_as_int(acc[i]), 0));
-        s1 += __int_as_float(max(__float_as_int(acc[i + 1]), 0));
+        const float t0 = __int_as_float(max(__float_as_int(acc[i]), 0)), t1 = __int_as_float(max(__float_as_int(acc[i + 1]), 0));
+        s0 += DROP ? t0 * keep[g][i] : t0;
+        s1 += DROP ? t1 * keep[g][i + 1] : t1;
       }
       return s0 + s1;
     };
@@ -1053,6 +1062,17 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
       }
       const int rw = valid ? rw_1 : -1;
       const int n_valid = (int)min((int64_t)64, p.n_edges - chunk * 64);      // scalar
+      if (DROP) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {                       // registers 4q .. 4q+3: four consecutive edges, one hash
+            const unsigned long long zd =
+                drop_hash4(p.drop_n.seed, p.drop_stream + 1, drop_msg_index(chunk * 64 + 32 * g + 8 * q + 4 * hi, k, p.n_edges) >> 2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) keep[g][4 * q + j] = drop_field(p.drop_n, zd, j) ? p.drop_n.inv_keep : 0.f;
+          }
+      }
       float lg0 = 0.f, lg1 = 0.f;
       if (want_logits && p.n_classes == 2) {                    // classifier on this edge (mpn.py:291-292): arithmetic now,
         // two scalar FMA chains, kept apart: paired up by the SLP vectoriser they become v_pk_fma_f32 with op_sel,
@@ -1121,7 +1141,7 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
           if (ra[g] < 0) break;
-          const float total = relu_sum(acc[g]);
+          const float total = relu_sum(acc[g], g);
           if (rb[g] < 0) {
             account(ra[g], total);
           } else {                                             // the first row's share through per-register lane masks
@@ -1131,7 +1151,8 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
               const int c = (i & 3) + 8 * (i >> 2);
               const unsigned long long in_a = (((ma[g] >> c) & 1u) ? 0xffffffffull : 0ull) |
                                               (((ma[g] >> (c + 4)) & 1u) ? 0xffffffff00000000ull : 0ull);
-              const float t = __int_as_float(max(__float_as_int(acc[g][i]), 0));
+              const float t0 = __int_as_float(max(__float_as_int(acc[g][i]), 0));
+              const float t = DROP ? t0 * keep[g][i] : t0;
               const float v = __builtin_amdgcn_inverse_ballot_w64(in_a) ? t : 0.f;
               if (i & 1) sa1 += v; else sa0 += v;
             }
@@ -1167,7 +1188,7 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
               const int r = __shfl(rw, 32 * g + off, 64);
               if (r >= 0 && ((gm >> off) & 1u)) {
                 const float c0 = fmaf(sk, p.Q[(int64_t)r * kH + k], cb);
-                unsafeAtomicAdd(p.h_acc + (int64_t)r * kH + k, fmaxf(acc[i] + c0, 0.f));
+                unsafeAtomicAdd(p.h_acc + (int64_t)r * kH + k, DROP ? fmaxf(acc[i] + c0, 0.f) * keep[g][i] : fmaxf(acc[i] + c0, 0.f));
               }
             }
             continue;
@@ -1183,7 +1204,7 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
             float sacc = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-              const float t = fmaxf(acc[i] + c0, 0.f);
+              const float t = DROP ? fmaxf(acc[i] + c0, 0.f) * keep[g][i] : fmaxf(acc[i] + c0, 0.f);
               sacc += ((mine >> ((i & 3) + 8 * (i >> 2))) & 1u) ? t : 0.f;
             }
             account(r, sacc);
@@ -1655,7 +1676,8 @@ void launch_pass_b(const RoundParams& p, hipStream_t s) {
 // per row.  MTMC_PASS_C_WALK=1 keeps the walk everywhere (A/B).
 int plan_pass_c(int agg, bool deterministic, bool dropout, int64_t n_edges, int64_t n_nodes, double avg_degree) {
   const Knobs& kn = knobs();
-  if (kn.pass_c_walk || agg == 2 || dropout || avg_degree < 24.0) return 0;
+  if (kn.pass_c_walk || agg == 2 || avg_degree < 24.0) return 0;
+  if (dropout && (n_edges > kSmallEdges || deterministic)) return 0;     // Dropout: only the few-edge any-order kernel knows it
   // many-edge lists: the sorted kernel (also in deterministic mode) -- unless the call gets the any-order kernel instead
   // (MTMC_PASS_C_GENERAL, or >= 2^24 GLOBAL node rows, reachable with row-sharded multi-GPU calls): that one only knows
   // float atomics, so a deterministic call keeps the walk there (its carry[] is what agg_fixup_kernel adds up)
@@ -1708,7 +1730,8 @@ void launch_pass_c(const RoundParams& p0, hipStream_t s) {
     const int span_c = span_env > 0 ? span_env : (p.mfma_c == 2 ? 1 : 8);
     const int64_t spans = ((p.n_edges + 63) / 64 + span_c - 1) / span_c, blocks = (spans + 3) / 4;
     const int cap = max_blocks < 256 * 3 ? max_blocks : 256 * 3;           // 130 registers: three blocks per CU
-    hipLaunchKernelGGL(pass_c_mfma_kernel, dim3((int)(blocks > cap ? cap : blocks)), dim3(256), 0, s, p, span_c);
+    if (p.drop_n.on) hipLaunchKernelGGL(pass_c_mfma_kernel<true>, dim3((int)(blocks > cap ? cap : blocks)), dim3(256), 0, s, p, span_c);
+    else hipLaunchKernelGGL(pass_c_mfma_kernel<false>, dim3((int)(blocks > cap ? cap : blocks)), dim3(256), 0, s, p, span_c);
   }
   // (behind a matrix-core kernel the walk returns at once on sorted lists -- all but the workgroup that owns the < 64 edges
   //  behind the last whole chunk.  Round 5 launched it with 256 workgroups instead of up to 2048 there: the launch still

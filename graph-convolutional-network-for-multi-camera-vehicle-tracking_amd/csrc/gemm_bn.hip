@@ -94,10 +94,9 @@ __global__ __launch_bounds__(256) void gemm_bn_kernel(GemmParams p, int tiles_m,
         v.w = fmaxf(fmaf(v.w, s.w, t.w), 0.f);
         if (p.drop_in.on) {
           const unsigned long long idx = (unsigned long long)(m0 + r) * p.K + k_base + k0 + c4 * 4;
-          v.x = drop_apply(p.drop_in, p.drop_stream, idx, v.x);
-          v.y = drop_apply(p.drop_in, p.drop_stream, idx + 1, v.y);
-          v.z = drop_apply(p.drop_in, p.drop_stream, idx + 2, v.z);
-          v.w = drop_apply(p.drop_in, p.drop_stream, idx + 3, v.w);
+          float dv[4] = {v.x, v.y, v.z, v.w};
+          drop_apply4(p.drop_in, p.drop_stream, idx, dv);        // (idx % 4 == 0: one hash for the four)
+          v = make_float4(dv[0], dv[1], dv[2], dv[3]);
         }
       }
       *reinterpret_cast<float4*>(As + r * LDK + c4 * 4) = v;
@@ -285,10 +284,9 @@ __global__ __launch_bounds__(256) void gemm_bn_bf16x6_kernel(GemmParams p, int t
         v.w = fmaxf(fmaf(v.w, s.w, t.w), 0.f);
         if (p.drop_in.on) {
           const unsigned long long idx = (unsigned long long)(m0 + r) * p.K + k_base + k0 + c4 * 4;
-          v.x = drop_apply(p.drop_in, p.drop_stream, idx, v.x);
-          v.y = drop_apply(p.drop_in, p.drop_stream, idx + 1, v.y);
-          v.z = drop_apply(p.drop_in, p.drop_stream, idx + 2, v.z);
-          v.w = drop_apply(p.drop_in, p.drop_stream, idx + 3, v.w);
+          float dv[4] = {v.x, v.y, v.z, v.w};
+          drop_apply4(p.drop_in, p.drop_stream, idx, dv);        // (idx % 4 == 0: one hash for the four)
+          v = make_float4(dv[0], dv[1], dv[2], dv[3]);
         }
       }
       put(As, BM, r, c4, v);
@@ -558,10 +556,9 @@ __global__ __launch_bounds__(256) void gemm_bn_f16x3_kernel(GemmParams p, int ti
         v.w = fmaxf(fmaf(v.w, s.w, t.w), 0.f);
         if (p.drop_in.on) {
           const unsigned long long idx = (unsigned long long)(m0 + r) * p.K + k_base + k0 + c4 * 4;
-          v.x = drop_apply(p.drop_in, p.drop_stream, idx, v.x);
-          v.y = drop_apply(p.drop_in, p.drop_stream, idx + 1, v.y);
-          v.z = drop_apply(p.drop_in, p.drop_stream, idx + 2, v.z);
-          v.w = drop_apply(p.drop_in, p.drop_stream, idx + 3, v.w);
+          float dv[4] = {v.x, v.y, v.z, v.w};
+          drop_apply4(p.drop_in, p.drop_stream, idx, dv);        // (idx % 4 == 0: one hash for the four)
+          v = make_float4(dv[0], dv[1], dv[2], dv[3]);
         }
       }
       put(As, PSA, r, c4, v, sa);

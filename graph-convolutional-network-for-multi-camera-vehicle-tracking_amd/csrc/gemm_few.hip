@@ -342,11 +342,17 @@ __global__ __launch_bounds__(512) void few_wave_kernel(FewWaveParams p) {
       const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
       const float tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        xv[s][j] = fmaxf(fmaf(x[j], sv[j], tv[j]), 0.f);
-        if (DROP) xv[s][j] = drop_apply(p.drop_in, p.drop_stream, (unsigned long long)arows[rb] * p.K + k0 + 32 * s + 8 * g + j, xv[s][j]);
-        m = fmaxf(m, xv[s][j]);
+      for (int j = 0; j < 8; ++j) xv[s][j] = fmaxf(fmaf(x[j], sv[j], tv[j]), 0.f);
+      if (DROP) {                                              // eight consecutive elements of a row: two hashes
+        const unsigned long long idx = (unsigned long long)arows[rb] * p.K + k0 + 32 * s + 8 * g;
+        float lo[4] = {xv[s][0], xv[s][1], xv[s][2], xv[s][3]}, hi[4] = {xv[s][4], xv[s][5], xv[s][6], xv[s][7]};
+        drop_apply4(p.drop_in, p.drop_stream, idx, lo);
+        drop_apply4(p.drop_in, p.drop_stream, idx + 4, hi);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { xv[s][j] = lo[j]; xv[s][4 + j] = hi[j]; }
       }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m = fmaxf(m, xv[s][j]);
     }
     m = wave_max_nonneg(m);
     if (rb == 0) FS_WAVE(2);                                    // A rows landed, activated, |.|max known

@@ -114,9 +114,12 @@ __global__ __launch_bounds__(256) void bwd_node_upd_kernel(BwdRoundParams p) {
     int cur = -1;
     float q = 0.f, dh = 0.f, hval = 0.f, dq_acc = 0.f;
     int winner = -1;
+    unsigned long long zd = 0;               // Dropout: the hash of four consecutive edges of this lane's channel (common.h)
     for (int j = 0; j < n_here; ++j) {
       const int r = tile_row[hw * 32 + j];
       const float4 v = tile_e[hw * 32 + j];
+      if (p.f.drop_n.on && (j & 3) == 0)
+        zd = drop_hash4(p.f.drop_n.seed, p.f.drop_stream + 1, drop_msg_index(base + hw * 32 + j, k, p.f.n_edges) >> 2);
       if (r != cur) {
         if (MODE == 1 && cur >= 0) unsafeAtomicAdd(p.g_Q + (int64_t)cur * kH + k, dq_acc);
         cur = r;
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256) void bwd_node_upd_kernel(BwdRoundParams p) {
       const float z2 = fmaf(a4[3], v.w, fmaf(a4[2], v.z, fmaf(a4[1], v.y, fmaf(a4[0], v.x, q + bk))));
       const float zh = (z2 - mu) * istd;
       const float y = fmaf(a4s[3], v.w, fmaf(a4s[2], v.z, fmaf(a4s[1], v.y, fmaf(a4s[0], v.x, fmaf(sk, q, cb)))));
-      const bool kept = drop_keep(p.f.drop_n, p.f.drop_stream + 1, (unsigned long long)eidx * kH + k);
+      const bool kept = !p.f.drop_n.on || drop_field(p.f.drop_n, zd, j & 3);
       const bool live = kept && y > 0.f;
       if (MODE == 2) {
         if (live && y * ik == hval) atomicMin(p.arg + (int64_t)r * kH + k, (int)eidx);
@@ -495,8 +498,9 @@ __global__ __launch_bounds__(256) void bwd_edge_enc_kernel(BwdEncParams p) {
       if (fe > 1) z = fmaf(wl.w1[k * fe + 1], a1, z);
       za[k] = z;
       zha[k] = (z - sh.mua[k]) * sh.ia[k];
-      u[k] = drop_apply(p.enc.drop, kDropEncEdge1, (unsigned long long)e * 4 + k, fmaxf(fmaf(z, af.s1[k], af.t1[k]), 0.f));
+      u[k] = fmaxf(fmaf(z, af.s1[k], af.t1[k]), 0.f);
     }
+    drop_apply4(p.enc.drop, kDropEncEdge1, (unsigned long long)e * 4, u);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float z = wl.b2[k];
@@ -504,8 +508,9 @@ __global__ __launch_bounds__(256) void bwd_edge_enc_kernel(BwdEncParams p) {
       for (int j = 0; j < 4; ++j) z = fmaf(wl.w2[k * 4 + j], u[j], z);
       zb[k] = z;
       zhb[k] = (z - sh.mub[k]) * sh.ib[k];
-      e0[k] = drop_apply(p.enc.drop, kDropEncEdge2, (unsigned long long)e * 4 + k, fmaxf(fmaf(z, af.s2[k], af.t2[k]), 0.f));
+      e0[k] = fmaxf(fmaf(z, af.s2[k], af.t2[k]), 0.f);
     }
+    drop_apply4(p.enc.drop, kDropEncEdge2, (unsigned long long)e * 4, e0);
     const float4 d4 = reinterpret_cast<const float4*>(p.g_e0)[e];
     const float de0[4] = {d4.x, d4.y, d4.z, d4.w};
     float gb[4];

@@ -89,7 +89,8 @@ def test_single_gpu_regimes(eng):
     det_small = eng.plan(450, 150_454, flags=_lib.F_DETERMINISTIC)
     assert det_small.pass_c == _lib.PASS_C_WALK         # few edges: fixed-order aggregation lives in the walk
     trn = eng.plan(440, 180_000, training=True)
-    assert trn.pass_c == _lib.PASS_C_WALK and not trn.lazy_edges     # Dropout in the node update; e' kept for the tape
+    assert trn.pass_c == _lib.PASS_C_MFMA_ANY and not trn.lazy_edges  # Dropout compiled into the few-edge matrix-core pass C; e' kept for the tape
+    assert eng.plan(1480, 1_642_800, training=True).pass_c == _lib.PASS_C_WALK       # (many-edge lists: Dropout stays on the walk)
     assert trn.enc_kernel == [_lib.GEMM_FEW_L0] + [_lib.GEMM_FEW_WAVE] * 3     # training forwards take the few-row kernels too (Dropout compiled in)
     assert eng.plan(440, 180_000, training=True, weight_cache=False).enc_kernel == [_lib.GEMM_INLOOP_64] * 4
 
