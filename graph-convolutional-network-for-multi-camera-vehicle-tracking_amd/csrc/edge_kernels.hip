@@ -921,7 +921,7 @@ __global__ __launch_bounds__(kTileC) void pass_c_kernel(RoundParams p) {
 // 64-edge chunks per wave span (runs are carried inside a span; one span per wave, so the grid balances itself)
 
 template <bool DROP>        // DROP (training, few-edge lists): the node update's Dropout on the messages, per accumulator register
-__global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int span_c) {
+__global__ __launch_bounds__(256, (DROP ? 3 : 1)) void pass_c_mfma_kernel(RoundParams p, int span_c) {   // DROP: 168 registers, three blocks per CU
   if (DROP) drop_resolve(p.drop_n);
   __shared__ double st[10 + 64];
   const int lane = threadIdx.x & 63;
@@ -1012,14 +1012,16 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
     // -0 have the sign bit set), and free of the canonicalising v_max_f32 x, x, x that fmaxf puts in front
     // DROP: keep[g][i] = 1/(1-p) or 0 for register i of group g (edge 64 chunk + 32 g + (i&3) + 8 (i>>2) + 4 hi, channel k:
     // drop_msg_index, what the walk and the backward hash too), taken once per chunk: eight hashes for the 32 registers
-    float keep[2][16];
+    unsigned keepbits[2] = {0u, 0u};                 // (bit i: register i kept -- one register instead of 32 factors)
+    const float ikn = DROP ? p.drop_n.inv_keep : 1.f;
+    auto keepf = [&](int g, int i) -> float { return ((keepbits[g] >> i) & 1u) ? ikn : 0.f; };
     auto relu_sum = [&](const f32x16c& acc, int g) -> float {
       float s0 = 0.f, s1 = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; i += 2) {
         const float t0 = __int_as_float(max(__float_as_int(acc[i]), 0)), t1 = __int_as_float(max(__float_as_int(acc[i + 1]), 0));
-        s0 += DROP ? t0 * keep[g][i] : t0;
-        s1 += DROP ? t1 * keep[g][i + 1] : t1;
+        s0 += DROP ? t0 * keepf(g, i) : t0;
+        s1 += DROP ? t1 * keepf(g, i + 1) : t1;
       }
       return s0 + s1;
     };
@@ -1063,6 +1065,7 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
       const int rw = valid ? rw_1 : -1;
       const int n_valid = (int)min((int64_t)64, p.n_edges - chunk * 64);      // scalar
       if (DROP) {
+        keepbits[0] = keepbits[1] = 0u;
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -1070,7 +1073,7 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
             const unsigned long long zd =
                 drop_hash4(p.drop_n.seed, p.drop_stream + 1, drop_msg_index(chunk * 64 + 32 * g + 8 * q + 4 * hi, k, p.n_edges) >> 2);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) keep[g][4 * q + j] = drop_field(p.drop_n, zd, j) ? p.drop_n.inv_keep : 0.f;
+            for (int j = 0; j < 4; ++j) keepbits[g] |= drop_field(p.drop_n, zd, j) ? (1u << (4 * q + j)) : 0u;
           }
       }
       float lg0 = 0.f, lg1 = 0.f;
@@ -1152,7 +1155,7 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
               const unsigned long long in_a = (((ma[g] >> c) & 1u) ? 0xffffffffull : 0ull) |
                                               (((ma[g] >> (c + 4)) & 1u) ? 0xffffffff00000000ull : 0ull);
               const float t0 = __int_as_float(max(__float_as_int(acc[g][i]), 0));
-              const float t = DROP ? t0 * keep[g][i] : t0;
+              const float t = DROP ? t0 * keepf(g, i) : t0;
               const float v = __builtin_amdgcn_inverse_ballot_w64(in_a) ? t : 0.f;
               if (i & 1) sa1 += v; else sa0 += v;
             }
@@ -1188,7 +1191,7 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
               const int r = __shfl(rw, 32 * g + off, 64);
               if (r >= 0 && ((gm >> off) & 1u)) {
                 const float c0 = fmaf(sk, p.Q[(int64_t)r * kH + k], cb);
-                unsafeAtomicAdd(p.h_acc + (int64_t)r * kH + k, DROP ? fmaxf(acc[i] + c0, 0.f) * keep[g][i] : fmaxf(acc[i] + c0, 0.f));
+                unsafeAtomicAdd(p.h_acc + (int64_t)r * kH + k, DROP ? fmaxf(acc[i] + c0, 0.f) * keepf(g, i) : fmaxf(acc[i] + c0, 0.f));
               }
             }
             continue;
@@ -1204,7 +1207,7 @@ __global__ __launch_bounds__(256) void pass_c_mfma_kernel(RoundParams p, int spa
             float sacc = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-              const float t = DROP ? fmaxf(acc[i] + c0, 0.f) * keep[g][i] : fmaxf(acc[i] + c0, 0.f);
+              const float t = DROP ? fmaxf(acc[i] + c0, 0.f) * keepf(g, i) : fmaxf(acc[i] + c0, 0.f);
               sacc += ((mine >> ((i & 3) + 8 * (i >> 2))) & 1u) ? t : 0.f;
             }
             account(r, sacc);
