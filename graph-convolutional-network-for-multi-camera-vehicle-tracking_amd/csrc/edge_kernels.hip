@@ -1739,7 +1739,14 @@ void launch_pass_c(const RoundParams& p0, hipStream_t s) {
   // (behind a matrix-core kernel the walk returns at once on sorted lists -- all but the workgroup that owns the < 64 edges
   //  behind the last whole chunk.  Round 5 launched it with 256 workgroups instead of up to 2048 there: the launch still
   //  took 5.3 us (5.1 before: it is the fixed cost of a dependent launch, not the dispatch of 2048 workgroups that return), and
-  //  an unsorted many-edge list would walk with an eighth of the workgroups -- reverted, profiles/r05_cfg4_kernel_stats.csv)
+  //  an unsorted many-edge list would walk with an eighth of the workgroups -- reverted, profiles/r05_cfg4_kernel_stats.csv.
+  //  With exactly ONE workgroup (-DMTMC_WALK_TAIL_GRID=1, same box, alternating): 5.60 / 5.67 us against 5.51 / 5.54 for the
+  //  full grid, profiles/r05_walk_grid1.txt)
+#ifdef MTMC_WALK_TAIL_GRID      // A/B builds: the walk behind the sorted kernel with this many workgroups
+  if (p.mfma_c == 3 || p.mfma_c == 4) {
+    hipLaunchKernelGGL(pass_c_kernel, dim3(MTMC_WALK_TAIL_GRID), dim3(kTileC), 0, s, p);
+  } else
+#endif
   if (p.mfma_c != 2) hipLaunchKernelGGL(pass_c_kernel, dim3(edge_grid(p.n_edges, kTileC)), dim3(kTileC), 0, s, p);
   if (p.det && p.agg != 2) {
     const int64_t blocks = (p.n_nodes + 7) / 8;
